@@ -1,0 +1,130 @@
+/*
+ * quantool_amd.h -- C ABI of the MI355X (gfx950) backend for quantool's GPTQ / AWQ /
+ * SmoothQuant per-linear calibration hot path.
+ *
+ * The reference (langtech-bsc/quantool) has no FFI for this path: its plugins hand the whole
+ * job to llmcompressor.oneshot (src/quantool/methods/llm_compressor/base.py:161).  Each entry
+ * point below therefore cites the upstream step it replaces by SURVEY.md section 8(a) row
+ * (a7..a14) and the reference line through which that step is reached.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says host;
+ *   - the caller owns every buffer; nothing persistent is allocated here.  Scratch comes in
+ *     through (workspace, workspace_bytes); sizes from the matching *_workspace_bytes();
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are
+ *     asynchronous and re-entrant per stream; the current HIP device is used;
+ *   - return value: QT_OK (0) or a negative qt_status; qt_last_error() gives a message for
+ *     the calling thread.  Nothing throws across this boundary;
+ *   - matrices are row-major; "ld" arguments are row strides in ELEMENTS.
+ */
+#ifndef QUANTOOL_AMD_H
+#define QUANTOOL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* qt_stream_t; /* hipStream_t */
+
+enum qt_status {
+    QT_OK = 0,
+    QT_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    QT_ERR_NOT_PD = -2,      /* Hessian not positive definite (host-side check helper) */
+    QT_ERR_WORKSPACE = -3,   /* workspace too small */
+    QT_ERR_HIP = -4,         /* a HIP runtime call failed */
+    QT_ERR_UNSUPPORTED = -5
+};
+
+enum qt_dtype { QT_F32 = 0, QT_BF16 = 1, QT_F16 = 2 };
+
+int qt_version(void);
+const char* qt_last_error(void);
+
+/* ---- a7  accumulate_hessian (GPTQ hook under base.py:161) ----------------------------------
+ * G[K,K] (fp32, lower triangle incl. diagonal tiles) += X^T X for X[n_tokens,K] bf16.
+ * The caller keeps the raw Gram sum G and the sample count n; upstream's running
+ * "H = H*n/(n+1) + (2/(n+1)) X^T X" equals (2/n)*G and is applied in qt_hessian_prepare.
+ * Requires K % 8 == 0, ldx % 8 == 0, X 16-byte aligned.  Deterministic (fixed split + ordered
+ * slab reduction, no atomics). */
+size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K);
+int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G,
+                      void* workspace, size_t workspace_bytes, qt_stream_t stream);
+
+/* ---- a12/a13  activation statistics (AWQ / SmoothQuant hooks under base.py:161) ------------
+ * abs_sum[K] += sum_t |x[t,k]|;  cmin[k] = min(cmin[k], min_t x);  cmax likewise.  Any of the
+ * three outputs may be NULL.  The caller initialises abs_sum = 0, cmin = +inf, cmax = -inf.
+ * X bf16 [n_tokens, K], K % 8 == 0.  Deterministic (ordered chunk reduction). */
+size_t qt_act_stats_workspace_bytes(int64_t n_tokens, int K);
+int qt_act_stats_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* abs_sum,
+                            float* cmin, float* cmax, void* workspace, size_t workspace_bytes,
+                            qt_stream_t stream);
+
+/* ---- a8/a9  dead columns, damping, activation ordering (quantize_weight, gptq.py:86) -------
+ * From the Gram sum G (lower triangle) and sample count n builds, in one pass,
+ *   Hd = P^T (2/n * G) P  with  dead = diag==0 -> 1,  Hd += percdamp*mean(diag) * I
+ * and writes A = flat-reversed Hd (A[i][j] = Hd[K-1-i][K-1-j]), upper triangle valid, which is
+ * what qt_cholesky_inverse_upper consumes.  perm (int32[K], sweep position -> original column)
+ * may be NULL (identity).  dead[K] (uint8, indexed by sweep position) and diag_out[K]
+ * (fp32 diag of 2/n*G in ORIGINAL order, before dead/damp; may be NULL) are outputs. */
+size_t qt_hessian_prepare_workspace_bytes(int K);
+int qt_hessian_prepare(const float* G, int K, int64_t n_samples, float percdamp,
+                       const int32_t* perm, float* A, uint8_t* dead, float* diag_out,
+                       void* workspace, size_t workspace_bytes, qt_stream_t stream);
+/* diag(2/n * G) only (input to the activation-ordering argsort). */
+int qt_hessian_diag(const float* G, int K, int64_t n_samples, float* diag_out, qt_stream_t stream);
+
+/* ---- a8  cholesky -> cholesky_inverse -> cholesky(upper) ------------------------------------
+ * Given A = flat-reversed damped Hessian (upper triangle read, destroyed), writes
+ * U = chol(Hd^-1, upper) [K,K] row-major (strict lower triangle zero-filled).
+ * Uses A = R^T R, U = flat-reverse(R^-T) (DESIGN.md "one factorisation instead of three").
+ * info (device int32): 0 ok, else 1-based index of the first non-positive pivot; the host
+ * applies upstream's LinAlgError fallback (U = I) when it is non-zero. */
+size_t qt_cholesky_inverse_upper_workspace_bytes(int K);
+int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
+                              size_t workspace_bytes, qt_stream_t stream);
+
+/* ---- a10  minmax observer -> calculate_qparams ----------------------------------------------
+ * W[R,K] (fp32 or bf16 by w_dtype) -> scale, zp [R, K/group_size] fp32.  group_size <= 0:
+ * channel-wise.  symmetric: scale = absmax/((qmax-qmin)/2), zp = 0.  scale_t / zp_t (may be
+ * NULL) receive the same values group-major [G, R], the layout qt_gptq_sweep reads (one
+ * coalesced load per column step: lanes are rows). */
+int qt_group_minmax_qparams(const void* W, int w_dtype, int R, int K, int64_t ldw, int group_size,
+                            int symmetric, int num_bits, float* scale, float* zp, float* scale_t,
+                            float* zp_t, qt_stream_t stream);
+
+/* W_f32[R,K] = float(W[:, perm]) with dead sweep positions zeroed (W = weight.clone().float();
+ * W[:, perm]; W[:, dead] = 0).  perm / dead may be NULL. */
+int qt_weight_gather_f32(const void* W, int w_dtype, int R, int K, int64_t ldw, const int32_t* perm,
+                         const uint8_t* dead, float* W_f32, qt_stream_t stream);
+
+/* ---- a11  the column sweep of quantize_weight -----------------------------------------------
+ * W[R,K] fp32 in sweep order (updated in place: error-compensated, then dequantised values),
+ * U[K,K] upper factor, scale_t/zp_t [G,R] fp32 (group-major, see qt_group_minmax_qparams),
+ * g_idx[K] int32 = group of each sweep position.
+ * Outputs Qt[K,R] int8 (integer levels, sweep-position major) and loss[R].
+ * blocksize must be 128 (upstream default) in this build.  Bit-exact against
+ * oracle/gptq_oracle.c:orc_gptq_sweep for identical inputs. */
+size_t qt_gptq_sweep_workspace_bytes(int R, int K, int blocksize);
+int qt_gptq_sweep(float* W, int R, int K, const float* U, const float* scale_t, const float* zp_t,
+                  int G, const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt,
+                  float* loss, void* workspace, size_t workspace_bytes, qt_stream_t stream);
+
+/* ---- a14  pack_to_int32 (save path, base.py:188) --------------------------------------------
+ * packed[R, ceil(K/8)] int32: nibble j of word w = level(column 8w+j) + 8.  col_src (int32[K],
+ * may be NULL) maps an output column to the sweep position holding it (undoes actorder). */
+int qt_pack_int4(const int8_t* Qt, int R, int K, const int32_t* col_src, int32_t* packed,
+                 qt_stream_t stream);
+
+/* Dequantised weights in original column order: out[r,c] = (q - zp[r,g(c)]) * scale[r,g(c)],
+ * out dtype by out_dtype (fp32/bf16); g_of_col int32[K] group of each ORIGINAL column. */
+int qt_dequantize(const int8_t* Qt, int R, int K, const int32_t* col_src, const float* scale,
+                  const float* zp, int G, const int32_t* g_of_col, void* out, int out_dtype,
+                  int64_t ldo, qt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUANTOOL_AMD_H */

@@ -1,0 +1,90 @@
+"""Builds libquantool_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+In-tree output: ``quantool_amd/lib/libquantool_hip.so`` (git-ignored, travels to the GPU box).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+PKG = CSRC.parent
+LIB_DIR = PKG / "lib"
+OBJ_DIR = CSRC / "_obj"
+LIB_PATH = LIB_DIR / "libquantool_hip.so"
+
+# -ffp-contract=off: the sweep / prepare kernels restate upstream's op-by-op fp32 arithmetic;
+# contraction to FMA would change roundings.  MFMA builtins are unaffected.
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-fPIC",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-fast-math",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _stamp(src: Path) -> str:
+    h = hashlib.sha1()
+    h.update(src.read_bytes())
+    for hdr in sorted(list(CSRC.glob("*.h")) + [PKG.parent / "include" / "quantool_amd.h"]):
+        h.update(hdr.read_bytes())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: Path) -> Path:
+    obj = OBJ_DIR / (src.stem + ".o")
+    stamp = OBJ_DIR / (src.stem + ".stamp")
+    want = _stamp(src)
+    if obj.exists() and stamp.exists() and stamp.read_text() == want:
+        return obj
+    cmd = [_hipcc(), *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{res.stdout}\n{res.stderr}")
+    if res.stderr.strip():
+        sys.stderr.write(res.stderr)
+    stamp.write_text(want)
+    return obj
+
+
+def build(verbose: bool = False) -> Path:
+    OBJ_DIR.mkdir(exist_ok=True)
+    LIB_DIR.mkdir(exist_ok=True)
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    newest = max(o.stat().st_mtime for o in objs)
+    if not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(f"built {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(verbose=True)

@@ -1,0 +1,52 @@
+// Shared helpers for the gfx950 kernels and their C-ABI wrappers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/quantool_amd.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define QT_LDS __attribute__((address_space(3)))
+#define QT_GLOBAL __attribute__((address_space(1)))
+
+void qt_set_error(const char* fmt, ...);
+
+#define QT_CHECK_ARG(cond, ...)         \
+    do {                                \
+        if (!(cond)) {                  \
+            qt_set_error(__VA_ARGS__);  \
+            return QT_ERR_INVALID;      \
+        }                               \
+    } while (0)
+
+#define QT_HIP(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            qt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                         __FILE__, __LINE__);                                     \
+            return QT_ERR_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+#define QT_LAUNCH_CHECK()                                                         \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) {                                                   \
+            qt_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                     \
+            return QT_ERR_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+static inline size_t qt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+__device__ __forceinline__ float qt_bf16_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned)h) << 16);
+}

@@ -1,0 +1,97 @@
+// a8/a9: Hessian post-processing ahead of the factorisation (upstream
+// quantize_weight: H[dead,dead]=1, damp = percdamp*mean(diag H), H += damp I, optional
+// activation-order permutation).  HBM-bound single passes.
+#include "common.h"
+
+namespace {
+
+// One workgroup.  diag h[s] = c * G[p[s]][p[s]];  dead[s] = (h == 0);  mean over (dead ? 1 : h)
+// carried in fp64;  damp = fp32(percdamp) * fp32(mean).  stats[0] = damp.
+__global__ __launch_bounds__(1024) void diag_stats_kernel(const float* __restrict__ G, int K, float c,
+                                                          float percdamp, const int32_t* __restrict__ perm,
+                                                          uint8_t* __restrict__ dead, float* __restrict__ diag_out,
+                                                          float* __restrict__ stats) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const int o = perm ? perm[i] : i;
+        const float h = G[(size_t)o * K + o] * c;
+        const bool dd = (h == 0.0f);
+        dead[i] = dd ? 1 : 0;
+        s += dd ? 1.0 : (double)h;
+    }
+    if (diag_out) {
+        for (int i = threadIdx.x; i < K; i += blockDim.x) diag_out[i] = G[(size_t)i * K + i] * c;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mean = (float)(red[0] / (double)K);
+        stats[0] = percdamp * mean;
+    }
+}
+
+// A[i][j] (j >= i) = Hd[a][b], a = K-1-i >= b = K-1-j;  Hd = P^T (c G) P, dead diag -> 1, + damp I.
+__global__ __launch_bounds__(256) void build_flipped_kernel(const float* __restrict__ G, int K, float c,
+                                                            const int32_t* __restrict__ perm,
+                                                            const uint8_t* __restrict__ dead,
+                                                            const float* __restrict__ stats, float* __restrict__ A) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= K || j < i) return;
+    const int a = K - 1 - i, b = K - 1 - j;
+    const int pa = perm ? perm[a] : a, pb = perm ? perm[b] : b;
+    const int hi = pa > pb ? pa : pb, lo = pa > pb ? pb : pa;
+    float v = G[(size_t)hi * K + lo] * c;
+    if (a == b) {
+        if (dead[a]) v = 1.0f;
+        v = v + stats[0];
+    }
+    A[(size_t)i * K + j] = v;
+}
+
+__global__ __launch_bounds__(256) void diag_only_kernel(const float* __restrict__ G, int K, float c,
+                                                        float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) out[i] = G[(size_t)i * K + i] * c;
+}
+
+}  // namespace
+
+extern "C" size_t qt_hessian_prepare_workspace_bytes(int K) {
+    (void)K;
+    return 512;
+}
+
+extern "C" int qt_hessian_prepare(const float* G, int K, int64_t n_samples, float percdamp, const int32_t* perm,
+                                  float* A, uint8_t* dead, float* diag_out, void* workspace, size_t workspace_bytes,
+                                  qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(G && A && dead && K > 0 && n_samples > 0, "qt_hessian_prepare: bad arguments");
+    if (!workspace || workspace_bytes < 512) {
+        qt_set_error("qt_hessian_prepare: workspace %zu < required 512", workspace_bytes);
+        return QT_ERR_WORKSPACE;
+    }
+    float* stats = (float*)qt_align_up((size_t)workspace, 256);
+    const float c = (float)(2.0 / (double)n_samples);
+    hipLaunchKernelGGL(diag_stats_kernel, dim3(1), dim3(1024), 0, stream, G, K, c, percdamp, perm, dead, diag_out,
+                       stats);
+    QT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(build_flipped_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, G, K, c, perm,
+                       (const uint8_t*)dead, (const float*)stats, A);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_hessian_diag(const float* G, int K, int64_t n_samples, float* diag_out, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(G && diag_out && K > 0 && n_samples > 0, "qt_hessian_diag: bad arguments");
+    const float c = (float)(2.0 / (double)n_samples);
+    hipLaunchKernelGGL(diag_only_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, G, K, c, diag_out);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}

@@ -1,0 +1,163 @@
+// See sgemm_tn.h.  256 threads = 4 waves (2x2); each wave owns a (BM/2)x(BN/2) block of
+// 32x32 MFMA accumulators.  Operand panels [BK][BM] / [BK][BN] are register-staged into a
+// double-buffered LDS image (rows contiguous, so fragment reads are conflict-free b32 reads of
+// 32 consecutive floats per lane half) and zero-filled at every edge, so any M, N, k works.
+#include "sgemm_tn.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {
+    constexpr int WM = BM / 64, WN = BN / 64;  // 32x32 sub-tiles per wave in m / n
+    constexpr int A4 = BK * BM / 4 / NT;       // float4 loads per thread for A
+    constexpr int B4 = BK * BN / 4 / NT;
+    static_assert(A4 >= 1 && B4 >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    int k_begin = 0;
+    if (p.k_mode == SG_K_FROM_N0) k_begin = n0 / BK * BK;
+    const int k_end = p.kdim;
+
+    const bool a_vec = (p.lda % 4 == 0) && (((uintptr_t)p.A & 15) == 0);
+    const bool b_vec = (p.ldb % 4 == 0) && (((uintptr_t)p.B & 15) == 0);
+
+    f32x4 ra[A4], rb[B4];
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < A4; ++r) {
+            const int idx = tid + NT * r;
+            const int kr = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
+            const int k = k0 + kr, m = m0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < k_end) {
+                const float* src = p.A + (size_t)k * p.lda + m;
+                if (a_vec && m + 3 < p.M) {
+                    v = *(const f32x4*)src;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m + e < p.M) v[e] = src[e];
+                }
+            }
+            ra[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < B4; ++r) {
+            const int idx = tid + NT * r;
+            const int kr = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+            const int k = k0 + kr, n = n0 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < k_end) {
+                const float* src = p.B + (size_t)k * p.ldb + n;
+                if (b_vec && n + 3 < p.N) {
+                    v = *(const f32x4*)src;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) v[e] = src[e];
+                }
+            }
+            rb[r] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < A4; ++r) {
+            const int idx = tid + NT * r;
+            *(f32x4*)&As[buf][idx / (BM / 4)][(idx % (BM / 4)) * 4] = ra[r];
+        }
+#pragma unroll
+        for (int r = 0; r < B4; ++r) {
+            const int idx = tid + NT * r;
+            *(f32x4*)&Bs[buf][idx / (BN / 4)][(idx % (BN / 4)) * 4] = rb[r];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nsteps = (k_end - k_begin + BK - 1) / BK;
+    if (nsteps > 0) {
+        gload(k_begin);
+        lstore(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nsteps) gload(k_begin + (s + 1) * BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a[WM], b[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[i] = As[buf][2 * kk + h][wave_m * (BM / 2) + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[j] = Bs[buf][2 * kk + h][wave_n * (BN / 2) + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (s + 1 < nsteps) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wave_m * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
+                if (row < p.M && col < p.N) {
+                    float v = acc[i][j][r];
+                    if (MODE == SG_MODE_SUB) v = p.Cin[(size_t)row * p.ldcin + col] - v;
+                    if (MODE == SG_MODE_NEG) v = -v;
+                    p.Cout[(size_t)row * p.ldcout + col] = v;
+                }
+            }
+}
+
+template <int BM, int BN>
+int launch(const SgemmArgs& a, hipStream_t stream) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
+    switch (a.mode) {
+        case SG_MODE_SUB:
+            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB>), grid, dim3(NT), 0, stream, a);
+            break;
+        case SG_MODE_SET:
+            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SET>), grid, dim3(NT), 0, stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_NEG>), grid, dim3(NT), 0, stream, a);
+            break;
+    }
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+}  // namespace
+
+int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0) return QT_OK;
+    const long big_tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    // fewer than ~1.5 rounds of 128x128 tiles on 256 CUs: use 64x64 tiles for 4x the workgroups
+    if (big_tiles >= 384) return launch<128, 128>(a, stream);
+    return launch<64, 64>(a, stream);
+}

@@ -1,0 +1,200 @@
+// a11: the GPTQ column sweep (upstream quantize_weight's block loop,
+// reached through gptq.py:86 / base.py:161).
+//
+// Rows of W are independent given U, so one lane owns one row.  Per 128-column block:
+//   sweep_block_kernel : the 128 sequential quantise / error-feedback steps.  The U block and
+//                        the lane's 128 weights live in LDS; the active 32-column sub-block
+//                        lives in registers (statically indexed), the other columns receive
+//                        rank-32 updates with float4 broadcasts of U.  Per element the update
+//                        sequence is exactly upstream's: ascending source column, each step
+//                        "w = w - (err * u)" with two roundings (no contraction).
+//   sgemm_tn (SUB)     : W[:, i2:] -= Err1 @ U[i1:i2, i2:] as an ascending-k fmaf chain from 0
+//                        on the f32 MFMA, then one subtraction -- the oracle's fixed order.
+// Bit-exact against oracle/gptq_oracle.c:orc_gptq_sweep.
+#include "common.h"
+#include "sgemm_tn.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int BS = 128;    // upstream block_size default
+constexpr int SB = 32;     // register sub-block
+constexpr int ROWS = 128;  // rows (lanes) per workgroup: 2 waves
+constexpr size_t SWEEP_LDS = (size_t)(BS * BS + BS * ROWS + 2 * BS) * sizeof(float);
+
+__global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W, int R, int K,
+                                                           const float* __restrict__ U,
+                                                           const float* __restrict__ scale_t,
+                                                           const float* __restrict__ zp_t,
+                                                           const int32_t* __restrict__ g_idx, int i1, int cnt,
+                                                           float qmin, float qmax, int8_t* __restrict__ Qt,
+                                                           float* __restrict__ ErrT, float* __restrict__ loss) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Un = sm;                  // [BS][BS]   Un[i][j] = U[i1+i][i1+j], zero outside j>=i / cnt
+    float* wl = sm + BS * BS;        // [BS cols][ROWS]
+    float* dd = wl + BS * ROWS;      // [BS] diag, [BS] diag^2
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x * ROWS + tid;
+    const bool valid = row < R;
+    const int rowc = valid ? row : R - 1;
+
+    for (int e = tid; e < BS * BS; e += ROWS) {
+        const int i = e / BS, j = e % BS;
+        float v = 0.0f;
+        if (i < cnt && j < cnt && j >= i) v = U[(size_t)(i1 + i) * K + (i1 + j)];
+        Un[e] = v;
+    }
+    {
+        const float d = (tid < cnt) ? U[(size_t)(i1 + tid) * K + (i1 + tid)] : 1.0f;
+        dd[tid] = d;
+        dd[BS + tid] = d * d;
+    }
+    {
+        const float* wrow = W + (size_t)rowc * K + i1;
+        for (int c = 0; c < BS; c += 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c + 3 < cnt) {
+                v = *(const f32x4*)(wrow + c);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < cnt) v[e] = wrow[c + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wl[(c + e) * ROWS + tid] = v[e];
+        }
+    }
+    __syncthreads();
+
+    float blk_loss = 0.0f;
+    for (int sb = 0; sb < BS / SB; ++sb) {
+        const int cb = sb * SB;
+        if (cb >= cnt) break;
+        float w[SB], er[SB], sc[SB], zz[SB];
+#pragma unroll
+        for (int t = 0; t < SB; ++t) w[t] = wl[(cb + t) * ROWS + tid];
+#pragma unroll
+        for (int t = 0; t < SB; ++t) {
+            const int c = cb + t;
+            const int g = (c < cnt) ? g_idx[i1 + c] : g_idx[i1];
+            sc[t] = scale_t[(size_t)g * R + rowc];
+            zz[t] = zp_t[(size_t)g * R + rowc];
+        }
+#pragma unroll
+        for (int t = 0; t < SB; ++t) {
+            const int c = cb + t;
+            {  // columns >= cnt of a ragged last block run as inert padding (w=0, U=0, d=1)
+                const float d = dd[c], d2 = dd[BS + c];
+                const float wv = w[t];
+                float x = wv / sc[t];
+                x = x + zz[t];
+                x = fminf(fmaxf(x, qmin), qmax);
+                const float q = rintf(x);
+                const float dq = (q - zz[t]) * sc[t];
+                const float diff = wv - dq;
+                blk_loss = blk_loss + (diff * diff) / d2;
+                const float e = diff / d;
+                er[t] = e;
+                w[t] = dq;
+                if (valid && c < cnt) {
+                    Qt[(size_t)(i1 + c) * R + row] = (int8_t)q;
+                    ErrT[(size_t)c * R + row] = e;
+                }
+                const float* urow = Un + c * BS + cb;
+#pragma unroll
+                for (int u = t + 1; u < SB; ++u) {
+                    const float pr = e * urow[u];
+                    w[u] = w[u] - pr;
+                }
+            }
+            // keep each column step's LDS broadcasts next to their use (without this hipcc
+            // hoists all 496 U reads of the triangle and spills)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // dequantised values of this sub-block back to W (upstream: W[:, i1:i2] = Q1)
+        if (valid) {
+            float* wrow = W + (size_t)row * K + i1 + cb;
+#pragma unroll
+            for (int t = 0; t < SB; t += 4) {
+                if (cb + t + 3 < cnt) {
+                    f32x4 v = {w[t], w[t + 1], w[t + 2], w[t + 3]};
+                    *(f32x4*)(wrow + t) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (cb + t + e < cnt) wrow[t + e] = w[t + e];
+                }
+            }
+        }
+        // rank-32 update of the block's remaining columns (ascending source column per element)
+        for (int j4 = cb + SB; j4 < cnt; j4 += 4) {
+            float wj[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wj[e] = wl[(j4 + e) * ROWS + tid];
+#pragma unroll
+            for (int t = 0; t < SB; ++t) {
+                const f32x4 u = *(const f32x4*)(Un + (cb + t) * BS + j4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pr = er[t] * u[e];
+                    wj[e] = wj[e] - pr;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wl[(j4 + e) * ROWS + tid] = wj[e];
+        }
+    }
+    if (valid) loss[row] = loss[row] + blk_loss / 2.0f;
+}
+
+}  // namespace
+
+extern "C" size_t qt_gptq_sweep_workspace_bytes(int R, int K, int blocksize) {
+    (void)K;
+    if (R <= 0 || blocksize <= 0) return 0;
+    return (size_t)blocksize * R * 4 + 256;  // ErrT[blocksize][R]
+}
+
+extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float* scale_t, const float* zp_t, int G,
+                             const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt, float* loss,
+                             void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && U && scale_t && zp_t && g_idx && Qt && loss, "qt_gptq_sweep: null pointer");
+    QT_CHECK_ARG(R > 0 && K > 0 && G > 0, "qt_gptq_sweep: bad shape R=%d K=%d G=%d", R, K, G);
+    QT_CHECK_ARG(blocksize == BS, "qt_gptq_sweep: blocksize=%d unsupported (this build: 128)", blocksize);
+    QT_CHECK_ARG(num_bits >= 2 && num_bits <= 8, "qt_gptq_sweep: num_bits=%d", num_bits);
+    QT_CHECK_ARG(K % 4 == 0 && ((uintptr_t)W & 15) == 0, "qt_gptq_sweep: K %% 4 and 16-byte aligned W required");
+    const size_t need = qt_gptq_sweep_workspace_bytes(R, K, blocksize);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_gptq_sweep: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    float* ErrT = (float*)qt_align_up((size_t)workspace, 256);
+    const float qmin = -(float)(1 << (num_bits - 1)), qmax = (float)((1 << (num_bits - 1)) - 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        QT_HIP(hipFuncSetAttribute((const void*)sweep_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)SWEEP_LDS));
+        attr_set = true;
+    }
+    QT_HIP(hipMemsetAsync(loss, 0, (size_t)R * 4, stream));
+    for (int i1 = 0; i1 < K; i1 += BS) {
+        const int i2 = (i1 + BS < K) ? i1 + BS : K;
+        const int cnt = i2 - i1;
+        hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R, K, U,
+                           scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, ErrT, loss);
+        QT_LAUNCH_CHECK();
+        if (i2 < K) {
+            SgemmArgs g;
+            g.A = ErrT; g.lda = R;
+            g.B = U + (size_t)i1 * K + i2; g.ldb = K;
+            g.Cin = W + i2; g.ldcin = K;
+            g.Cout = W + i2; g.ldcout = K;
+            g.M = R; g.N = K - i2; g.kdim = cnt; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+            const int rc = qt_sgemm_tn(g, stream);
+            if (rc) return rc;
+        }
+    }
+    return QT_OK;
+}

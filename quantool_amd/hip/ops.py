@@ -1,0 +1,257 @@
+"""Thin torch-tensor wrappers over the C ABI (``include/quantool_amd.h``).
+
+torch is plumbing here: device memory, the current HIP stream and shape checks before a raw
+pointer crosses the boundary (a wrong shape in a hand-written kernel is a GPU fault, so every
+assumption the kernels make is asserted on the host first).  No arithmetic happens in torch.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import QT_BF16, QT_F32, check, load
+
+_WS_CACHE: dict = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return QT_F32
+    if t.dtype == torch.bfloat16:
+        return QT_BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (fp32 / bf16 only)")
+
+
+def _req(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor (no CPU path exists)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name} must be {ndim}-d, got shape {tuple(t.shape)}")
+
+
+def workspace(nbytes: int, device, tag: str = "default") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, tag); reused across calls on the same stream."""
+    key = (str(device), tag)
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = buf
+    return buf
+
+
+def release_workspaces() -> None:
+    _WS_CACHE.clear()
+
+
+# ---- a7 -----------------------------------------------------------------------------------
+def xtx_accumulate(X: torch.Tensor, G: torch.Tensor) -> None:
+    """G[K,K] fp32 (lower triangle) += X^T X for X[..., K] bf16 (leading dims flattened)."""
+    lib = load()
+    _req(X, torch.bfloat16, "X")
+    _req(G, torch.float32, "G", 2)
+    K = G.shape[0]
+    if G.shape[1] != K or not G.is_contiguous():
+        raise ValueError("G must be contiguous [K, K]")
+    if X.shape[-1] != K:
+        raise ValueError(f"X last dim {X.shape[-1]} != K {K}")
+    X2 = X.reshape(-1, K)
+    if X2.stride(1) != 1:
+        X2 = X2.contiguous()
+    n = X2.shape[0]
+    if n == 0:
+        return
+    ldx = X2.stride(0) if n > 1 else K
+    nbytes = lib.qt_xtx_workspace_bytes(n, K)
+    ws = workspace(nbytes, X.device, "xtx")
+    check("qt_xtx_accumulate", lib.qt_xtx_accumulate(X2.data_ptr(), n, K, ldx, G.data_ptr(), ws.data_ptr(),
+                                                     ws.numel(), _stream()))
+
+
+# ---- a12 / a13 ----------------------------------------------------------------------------
+def act_stats_accumulate(X: torch.Tensor, abs_sum: Optional[torch.Tensor] = None,
+                         cmin: Optional[torch.Tensor] = None, cmax: Optional[torch.Tensor] = None) -> None:
+    lib = load()
+    _req(X, torch.bfloat16, "X")
+    K = X.shape[-1]
+    X2 = X.reshape(-1, K)
+    if X2.stride(1) != 1:
+        X2 = X2.contiguous()
+    n = X2.shape[0]
+    for name, t in (("abs_sum", abs_sum), ("cmin", cmin), ("cmax", cmax)):
+        if t is not None:
+            _req(t, torch.float32, name, 1)
+            if t.numel() != K or not t.is_contiguous():
+                raise ValueError(f"{name} must be contiguous [K]")
+    if n == 0:
+        return
+    ldx = X2.stride(0) if n > 1 else K
+    ws = workspace(lib.qt_act_stats_workspace_bytes(n, K), X.device, "stats")
+    check("qt_act_stats_accumulate", lib.qt_act_stats_accumulate(
+        X2.data_ptr(), n, K, ldx, _ptr(abs_sum), _ptr(cmin), _ptr(cmax), ws.data_ptr(), ws.numel(), _stream()))
+
+
+# ---- a8 / a9 ------------------------------------------------------------------------------
+def hessian_diag(G: torch.Tensor, n_samples: int) -> torch.Tensor:
+    lib = load()
+    _req(G, torch.float32, "G", 2)
+    K = G.shape[0]
+    out = torch.empty(K, dtype=torch.float32, device=G.device)
+    check("qt_hessian_diag", lib.qt_hessian_diag(G.data_ptr(), K, n_samples, out.data_ptr(), _stream()))
+    return out
+
+
+def hessian_prepare(G: torch.Tensor, n_samples: int, percdamp: float, perm: Optional[torch.Tensor] = None,
+                    A_out: Optional[torch.Tensor] = None):
+    """Returns (A flipped+damped [K,K] fp32 upper-valid, dead uint8[K], diag fp32[K])."""
+    lib = load()
+    _req(G, torch.float32, "G", 2)
+    K = G.shape[0]
+    if not G.is_contiguous() or G.shape[1] != K:
+        raise ValueError("G must be contiguous [K, K]")
+    if perm is not None:
+        _req(perm, torch.int32, "perm", 1)
+        if perm.numel() != K or not perm.is_contiguous():
+            raise ValueError("perm must be contiguous int32[K]")
+    A = A_out if A_out is not None else torch.empty((K, K), dtype=torch.float32, device=G.device)
+    _req(A, torch.float32, "A", 2)
+    if A.shape != (K, K) or not A.is_contiguous():
+        raise ValueError("A must be contiguous [K, K]")
+    dead = torch.empty(K, dtype=torch.uint8, device=G.device)
+    diag = torch.empty(K, dtype=torch.float32, device=G.device)
+    ws = workspace(lib.qt_hessian_prepare_workspace_bytes(K), G.device, "prep")
+    check("qt_hessian_prepare", lib.qt_hessian_prepare(G.data_ptr(), K, int(n_samples), float(percdamp), _ptr(perm),
+                                                       A.data_ptr(), dead.data_ptr(), diag.data_ptr(), ws.data_ptr(),
+                                                       ws.numel(), _stream()))
+    return A, dead, diag
+
+
+def cholesky_inverse_upper(A: torch.Tensor, U_out: Optional[torch.Tensor] = None):
+    """A (flipped damped Hessian, destroyed) -> (U upper [K,K] fp32, info int32[1] device)."""
+    lib = load()
+    _req(A, torch.float32, "A", 2)
+    K = A.shape[0]
+    if A.shape != (K, K) or not A.is_contiguous():
+        raise ValueError("A must be contiguous [K, K]")
+    U = U_out if U_out is not None else torch.empty((K, K), dtype=torch.float32, device=A.device)
+    if U.shape != (K, K) or not U.is_contiguous() or U.dtype != torch.float32:
+        raise ValueError("U must be contiguous fp32 [K, K]")
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    ws = workspace(lib.qt_cholesky_inverse_upper_workspace_bytes(K), A.device, "chol")
+    check("qt_cholesky_inverse_upper", lib.qt_cholesky_inverse_upper(A.data_ptr(), K, U.data_ptr(), info.data_ptr(),
+                                                                     ws.data_ptr(), ws.numel(), _stream()))
+    return U, info
+
+
+# ---- a10 ----------------------------------------------------------------------------------
+def group_minmax_qparams(W: torch.Tensor, group_size: int, symmetric: bool = True, num_bits: int = 4):
+    """Returns (scale[R,G], zp[R,G], scale_t[G,R], zp_t[G,R]) fp32."""
+    lib = load()
+    if W.dim() != 2 or not W.is_cuda or W.stride(1) != 1:
+        raise ValueError("W must be a 2-d device tensor with unit column stride")
+    R, K = W.shape
+    gs = K if group_size <= 0 else group_size
+    if K % gs:
+        raise ValueError(f"K={K} not divisible by group_size={gs}")
+    G = K // gs
+    dev = W.device
+    scale = torch.empty((R, G), dtype=torch.float32, device=dev)
+    zp = torch.empty((R, G), dtype=torch.float32, device=dev)
+    scale_t = torch.empty((G, R), dtype=torch.float32, device=dev)
+    zp_t = torch.empty((G, R), dtype=torch.float32, device=dev)
+    check("qt_group_minmax_qparams", lib.qt_group_minmax_qparams(
+        W.data_ptr(), _dtype_code(W), R, K, W.stride(0), gs, int(bool(symmetric)), num_bits, scale.data_ptr(),
+        zp.data_ptr(), scale_t.data_ptr(), zp_t.data_ptr(), _stream()))
+    return scale, zp, scale_t, zp_t
+
+
+def weight_gather_f32(W: torch.Tensor, perm: Optional[torch.Tensor] = None, dead: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load()
+    if W.dim() != 2 or not W.is_cuda or W.stride(1) != 1:
+        raise ValueError("W must be a 2-d device tensor with unit column stride")
+    R, K = W.shape
+    if perm is not None:
+        _req(perm, torch.int32, "perm", 1)
+        assert perm.numel() == K and perm.is_contiguous()
+    if dead is not None:
+        _req(dead, torch.uint8, "dead", 1)
+        assert dead.numel() == K and dead.is_contiguous()
+    if out is None:
+        out = torch.empty((R, K), dtype=torch.float32, device=W.device)
+    assert out.shape == (R, K) and out.is_contiguous() and out.dtype == torch.float32
+    check("qt_weight_gather_f32", lib.qt_weight_gather_f32(W.data_ptr(), _dtype_code(W), R, K, W.stride(0),
+                                                           _ptr(perm), _ptr(dead), out.data_ptr(), _stream()))
+    return out
+
+
+# ---- a11 ----------------------------------------------------------------------------------
+def gptq_sweep(W: torch.Tensor, U: torch.Tensor, scale_t: torch.Tensor, zp_t: torch.Tensor, g_idx: torch.Tensor,
+               blocksize: int = 128, num_bits: int = 4):
+    """In-place on W (fp32 [R,K], sweep order).  Returns (Qt int8 [K,R], loss fp32 [R])."""
+    lib = load()
+    _req(W, torch.float32, "W", 2)
+    _req(U, torch.float32, "U", 2)
+    _req(scale_t, torch.float32, "scale_t", 2)
+    _req(zp_t, torch.float32, "zp_t", 2)
+    _req(g_idx, torch.int32, "g_idx", 1)
+    R, K = W.shape
+    G = scale_t.shape[0]
+    if not (W.is_contiguous() and U.is_contiguous() and scale_t.is_contiguous() and zp_t.is_contiguous()
+            and g_idx.is_contiguous()):
+        raise ValueError("all sweep operands must be contiguous")
+    if U.shape != (K, K) or scale_t.shape != (G, R) or zp_t.shape != (G, R) or g_idx.numel() != K:
+        raise ValueError("sweep operand shapes inconsistent")
+    Qt = torch.empty((K, R), dtype=torch.int8, device=W.device)
+    loss = torch.empty(R, dtype=torch.float32, device=W.device)
+    ws = workspace(lib.qt_gptq_sweep_workspace_bytes(R, K, blocksize), W.device, "sweep")
+    check("qt_gptq_sweep", lib.qt_gptq_sweep(W.data_ptr(), R, K, U.data_ptr(), scale_t.data_ptr(), zp_t.data_ptr(), G,
+                                             g_idx.data_ptr(), blocksize, num_bits, Qt.data_ptr(), loss.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _stream()))
+    return Qt, loss
+
+
+# ---- a14 ----------------------------------------------------------------------------------
+def pack_int4(Qt: torch.Tensor, col_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = load()
+    _req(Qt, torch.int8, "Qt", 2)
+    K, R = Qt.shape
+    assert Qt.is_contiguous()
+    if col_src is not None:
+        _req(col_src, torch.int32, "col_src", 1)
+        assert col_src.numel() == K and col_src.is_contiguous()
+    packed = torch.empty((R, (K + 7) // 8), dtype=torch.int32, device=Qt.device)
+    check("qt_pack_int4", lib.qt_pack_int4(Qt.data_ptr(), R, K, _ptr(col_src), packed.data_ptr(), _stream()))
+    return packed
+
+
+def dequantize(Qt: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, g_of_col: torch.Tensor,
+               col_src: Optional[torch.Tensor] = None, dtype=torch.float32) -> torch.Tensor:
+    lib = load()
+    _req(Qt, torch.int8, "Qt", 2)
+    K, R = Qt.shape
+    _req(scale, torch.float32, "scale", 2)
+    _req(zp, torch.float32, "zp", 2)
+    _req(g_of_col, torch.int32, "g_of_col", 1)
+    G = scale.shape[1]
+    assert scale.shape == (R, G) and zp.shape == (R, G) and g_of_col.numel() == K
+    assert Qt.is_contiguous() and scale.is_contiguous() and zp.is_contiguous() and g_of_col.is_contiguous()
+    if col_src is not None:
+        _req(col_src, torch.int32, "col_src", 1)
+        assert col_src.numel() == K and col_src.is_contiguous()
+    out = torch.empty((R, K), dtype=dtype, device=Qt.device)
+    check("qt_dequantize", lib.qt_dequantize(Qt.data_ptr(), R, K, _ptr(col_src), scale.data_ptr(), zp.data_ptr(), G,
+                                             g_of_col.data_ptr(), out.data_ptr(), _dtype_code(out), out.stride(0),
+                                             _stream()))
+    return out

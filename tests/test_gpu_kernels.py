@@ -1,0 +1,240 @@
+"""Parity of every HIP kernel against the CPU oracle, called through the C ABI (ctypes).
+
+Bars (DESIGN.md "Parity contract"): integer / index outputs bit-exact; fp32 outputs that
+restate an elementwise upstream op bit-exact; Gram matrix and the Cholesky factor within the
+tolerances written next to each assertion (their upstream counterparts are BLAS/LAPACK calls
+whose summation order torch does not fix).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import bf16_tensor_to_bits, bits_to_bf16_tensor, synth_activations, synth_weight
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from quantool_amd.hip import ops as _ops
+
+    return _ops
+
+
+# ------------------------------------------------------------------------------------- a7
+@pytest.mark.parametrize("n_tokens,K", [(64, 64), (200, 64), (1000, 384), (4096, 512), (777, 264), (130, 1032)])
+def test_xtx_matches_f64_gram(ops, oracle, dev, n_tokens, K):
+    xb = synth_activations(n_tokens, K, seed=n_tokens + K)
+    X = bits_to_bf16_tensor(xb, dev)
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    torch.cuda.synchronize()
+    Gt = oracle.gram_f64(xb)
+    got = np.tril(G.cpu().numpy().astype(np.float64))
+    want = np.tril(Gt)
+    # fp32 accumulation of n exact products: |err| <~ sqrt(n)*eps*sum|x_i x_j|; 1e-5 relative to
+    # the geometric mean of the diagonals is the north_star's "H within 1e-5" bar.
+    dscale = np.sqrt(np.outer(np.diag(Gt), np.diag(Gt)))
+    assert np.all(np.abs(got - want) <= 1e-5 * np.tril(dscale) + 1e-30)
+    # accumulate semantics: a second call adds
+    ops.xtx_accumulate(X, G)
+    torch.cuda.synchronize()
+    got2 = np.tril(G.cpu().numpy().astype(np.float64))
+    assert np.all(np.abs(got2 - 2 * want) <= 2e-5 * np.tril(dscale) + 1e-30)
+
+
+def test_xtx_is_deterministic_and_handles_3d_input(ops, dev):
+    torch.manual_seed(0)
+    X = torch.randn(4, 96, 256, device=dev).to(torch.bfloat16)
+    G1 = torch.zeros((256, 256), dtype=torch.float32, device=dev)
+    G2 = torch.zeros_like(G1)
+    ops.xtx_accumulate(X, G1)
+    ops.xtx_accumulate(X, G2)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.tril(G1), torch.tril(G2))
+
+
+def test_xtx_rejects_bad_shapes(ops, dev):
+    from quantool_amd.hip._lib import HipBackendError
+
+    X = torch.zeros((16, 12), dtype=torch.bfloat16, device=dev)
+    G = torch.zeros((12, 12), dtype=torch.float32, device=dev)
+    with pytest.raises(HipBackendError):
+        ops.xtx_accumulate(X, G)  # K % 8 != 0
+
+
+# ------------------------------------------------------------------------------------ a12/a13
+@pytest.mark.parametrize("n_tokens,K", [(50, 64), (1000, 264), (5000, 4096)])
+def test_act_stats(ops, oracle, dev, n_tokens, K):
+    xb = synth_activations(n_tokens, K, seed=7)
+    X = bits_to_bf16_tensor(xb, dev)
+    s = torch.zeros(K, dtype=torch.float32, device=dev)
+    mn = torch.full((K,), float("inf"), dtype=torch.float32, device=dev)
+    mx = torch.full((K,), float("-inf"), dtype=torch.float32, device=dev)
+    ops.act_stats_accumulate(X, s, mn, mx)
+    torch.cuda.synchronize()
+    xf = oracle.bf16_bits_to_f32(xb)
+    omn, omx = oracle.channel_minmax(xb)
+    assert np.array_equal(mn.cpu().numpy(), omn)  # min / max are exact
+    assert np.array_equal(mx.cpu().numpy(), omx)
+    want = np.abs(xf).astype(np.float64).sum(axis=0)
+    np.testing.assert_allclose(s.cpu().numpy(), want, rtol=2e-6 * np.sqrt(n_tokens))
+
+
+# ------------------------------------------------------------------------------------- a8/a9
+@pytest.mark.parametrize("K,with_perm,with_dead", [(64, False, False), (264, True, True), (512, True, False)])
+def test_hessian_prepare(ops, oracle, dev, K, with_perm, with_dead):
+    rng = np.random.default_rng(K)
+    n_tok, n_samples = 3 * K, 6
+    xb = synth_activations(n_tok, K, seed=K)
+    if with_dead:
+        xb[:, [3, K - 2]] = 0
+    X = bits_to_bf16_tensor(xb, dev)
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    perm_np = rng.permutation(K).astype(np.int32) if with_perm else None
+    perm = torch.from_numpy(perm_np).to(dev) if with_perm else None
+    A, dead, diag = ops.hessian_prepare(G, n_samples, 0.01, perm)
+    torch.cuda.synchronize()
+    Gl = np.tril(G.cpu().numpy())
+    Gfull = Gl + np.tril(Gl, -1).T
+    c = np.float32(2.0 / n_samples)
+    H = (Gfull * c).astype(np.float32)  # one fp32 multiply per element, as the kernel
+    np.testing.assert_array_equal(diag.cpu().numpy(), np.diag(H))
+    Hp = H[perm_np][:, perm_np] if with_perm else H
+    Hd, odead, damp = oracle.hessian_dead_and_damp(Hp, 0.01)
+    np.testing.assert_array_equal(dead.cpu().numpy().astype(bool), odead)
+    want = Hd[::-1, ::-1]
+    got = A.cpu().numpy()
+    iu = np.triu_indices(K, 1)
+    np.testing.assert_array_equal(got[iu], want[iu])  # off-diagonal: exact
+    # diagonal: +damp where the mean is an fp64 sum in a different order -> allow 1 ulp
+    np.testing.assert_allclose(np.diag(got), np.diag(want), rtol=2.4e-7)
+
+
+@pytest.mark.parametrize("K", [64, 128, 200, 384, 1024])
+def test_cholesky_inverse_upper(ops, oracle, dev, K):
+    xb = synth_activations(4 * K, K, seed=K + 1)
+    H = oracle.hessian_from_gram(oracle.gram_f64(xb), 8)
+    Hd, _, _ = oracle.hessian_dead_and_damp(H, 0.01)
+    A = torch.from_numpy(np.ascontiguousarray(Hd[::-1, ::-1])).to(dev)
+    U, info = ops.cholesky_inverse_upper(A)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    got = U.cpu().numpy()
+    assert np.all(np.tril(got, -1) == 0), "strict lower triangle must be zero-filled"
+    truth = oracle.cholesky_inverse_upper_f64(Hd)
+    U_lapack, ok = oracle.cholesky_inverse_upper_lapack(Hd)
+    assert ok
+    scale = np.abs(truth).max()
+    err_gpu = np.abs(got - truth).max() / scale
+    err_lapack = np.abs(U_lapack - truth).max() / scale
+    # The HIP path (one factorisation + one triangular inverse) must be at least as close to the
+    # fp64 factor as upstream's own fp32 LAPACK three-step sequence, within a factor of 4.
+    assert err_gpu <= max(4 * err_lapack, 5e-6), (err_gpu, err_lapack)
+    # and it must actually factor H^-1: U^T U Hd ~= I
+    resid = got.astype(np.float64).T @ got.astype(np.float64) @ Hd.astype(np.float64) - np.eye(K)
+    assert np.abs(resid).max() < 5e-3
+
+
+def test_cholesky_reports_non_pd(ops, dev):
+    K = 256
+    A = torch.eye(K, dtype=torch.float32, device=dev)
+    A[200, 200] = -1.0
+    U, info = ops.cholesky_inverse_upper(A)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 201  # 1-based position in the flipped matrix
+
+
+# ------------------------------------------------------------------------------------- a10
+@pytest.mark.parametrize("R,K,gs,sym,dtype", [(16, 256, 128, True, "f32"), (33, 384, 128, False, "f32"),
+                                             (8, 512, -1, True, "f32"), (16, 256, 64, True, "bf16")])
+def test_qparams_exact(ops, oracle, dev, R, K, gs, sym, dtype):
+    Wn = synth_weight(R, K, seed=R)
+    if dtype == "bf16":
+        bits = oracle.f32_to_bf16_bits(Wn)
+        Wn = oracle.bf16_bits_to_f32(bits)
+        W = bits_to_bf16_tensor(bits, dev)
+    else:
+        W = torch.from_numpy(Wn).to(dev)
+    scale, zp, scale_t, zp_t = ops.group_minmax_qparams(W, gs, sym, 4)
+    torch.cuda.synchronize()
+    os_, oz = oracle.minmax_qparams(Wn, gs, sym, 4)
+    np.testing.assert_array_equal(scale.cpu().numpy(), os_)
+    np.testing.assert_array_equal(zp.cpu().numpy(), oz)
+    np.testing.assert_array_equal(scale_t.cpu().numpy(), os_.T)
+    np.testing.assert_array_equal(zp_t.cpu().numpy(), oz.T)
+
+
+def test_weight_gather(ops, dev):
+    R, K = 20, 136
+    W = torch.randn(R, K, device=dev).to(torch.bfloat16)
+    perm = torch.randperm(K, device=dev).to(torch.int32)
+    dead = torch.zeros(K, dtype=torch.uint8, device=dev)
+    dead[5] = 1
+    out = ops.weight_gather_f32(W, perm, dead)
+    torch.cuda.synchronize()
+    want = W.float()[:, perm.long()]
+    want[:, 5] = 0
+    assert torch.equal(out, want)
+
+
+# ------------------------------------------------------------------------------------- a11
+def _sweep_case(oracle, R, K, gs, sym, actorder, seed):
+    Wn = synth_weight(R, K, seed=seed)
+    xb = synth_activations(2 * K, K, seed=seed + 1)
+    H = oracle.hessian_from_gram(oracle.gram_f64(xb), 4)
+    return Wn, H
+
+
+@pytest.mark.parametrize("R,K,gs,sym", [(16, 128, 128, True), (64, 256, 128, True), (130, 384, 128, True),
+                                        (200, 640, 128, False), (96, 200, -1, True), (257, 512, 64, True)])
+def test_sweep_bit_exact_given_same_U(ops, oracle, dev, R, K, gs, sym):
+    Wn, H = _sweep_case(oracle, R, K, gs, sym, None, seed=R + K)
+    Hd, dead, _ = oracle.hessian_dead_and_damp(H)
+    Un = oracle.cholesky_inverse_upper_f64(Hd).astype(np.float32)
+    scale, zp = oracle.minmax_qparams(Wn, gs, sym, 4)
+    rng = np.random.default_rng(0)
+    G = scale.shape[1]
+    g_idx = (np.arange(K) // (K if gs <= 0 else gs)).astype(np.int32)
+    g_idx = g_idx[rng.permutation(K)]  # as under activation ordering
+    Qo, Wo, lo = oracle.gptq_sweep_c(Wn, Un, scale, zp, g_idx, 128, 4)
+
+    W = torch.from_numpy(Wn.copy()).to(dev)
+    U = torch.from_numpy(Un).to(dev)
+    Qt, loss = ops.gptq_sweep(W, U, torch.from_numpy(np.ascontiguousarray(scale.T)).to(dev),
+                              torch.from_numpy(np.ascontiguousarray(zp.T)).to(dev),
+                              torch.from_numpy(g_idx).to(dev), 128, 4)
+    torch.cuda.synchronize()
+    q = Qt.cpu().numpy().T
+    assert np.array_equal(q, Qo), f"{(q != Qo).sum()} of {q.size} levels differ"
+    np.testing.assert_array_equal(W.cpu().numpy(), Wo)  # dequantised weights, bit-exact
+    np.testing.assert_allclose(loss.cpu().numpy(), lo, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------- a14
+@pytest.mark.parametrize("R,K,perm", [(16, 64, False), (70, 264, True), (64, 4096, True), (5, 20, False)])
+def test_pack_and_dequant_exact(ops, oracle, dev, R, K, perm):
+    rng = np.random.default_rng(R * K)
+    Q = rng.integers(-8, 8, size=(R, K)).astype(np.int8)  # levels in ORIGINAL column order
+    col_src_np = rng.permutation(K).astype(np.int32) if perm else None
+    # sweep-position-major storage: position col_src[c] holds original column c
+    Qpos = np.empty((K, R), np.int8)
+    src = col_src_np if perm else np.arange(K)
+    Qpos[src] = Q.T
+    Qt = torch.from_numpy(Qpos).to(dev)
+    cs = torch.from_numpy(col_src_np).to(dev) if perm else None
+    packed = ops.pack_int4(Qt, cs)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(packed.cpu().numpy(), oracle.pack_int4(Q))
+    assert np.array_equal(oracle.unpack_int4(packed.cpu().numpy(), K), Q)
+    gs = 4 if K % 4 == 0 else K
+    G = K // gs
+    scale = (rng.random((R, G)).astype(np.float32) + 0.1)
+    zp = rng.integers(-8, 8, size=(R, G)).astype(np.float32)
+    g_of_col = (np.arange(K) // gs).astype(np.int32)
+    out = ops.dequantize(Qt, torch.from_numpy(scale).to(dev), torch.from_numpy(zp).to(dev),
+                         torch.from_numpy(g_of_col).to(dev), cs, torch.float32)
+    torch.cuda.synchronize()
+    want = (Q.astype(np.float32) - zp[:, g_of_col]) * scale[:, g_of_col]
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
