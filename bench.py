@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: quantized weights/sec, GPTQ int4 g128, Llama-3-8B-shaped, 512 calibration
+samples x 384 tokens, on N MI355X (BASELINE.json `metric`, configs[1]).
+
+A "step" is the whole per-Linear hot path for ONE decoder layer (7 Linears, 218 103 808 weights):
+Gram accumulation X^T X over all 196 608 calibration tokens for each of the layer's 4 distinct
+inputs, Hessian prepare, Cholesky-inverse factor, the GPTQ block sweep (actorder=static, the
+upstream default) and int4 pack.  `--steps 32` is the whole 8B model.  Inputs (synthetic weights
+and activations) are resident in HBM before the timed region.
+
+Multi-GPU: decoder layers are independent units in this synthetic per-Linear mode, so every rank
+quantizes its own layers (weak scaling, no data-path collective) and rank 0 gathers the packed
+state over RCCL at the end of the timed region (north_star: "RCCL ... only to gather the final
+quantized state_dict").
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+N_SAMPLES = 512
+SEQ_LEN = 384
+MODEL = "llama-3-8b"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_activations(n_tokens: int, K: int, seed: int, device) -> torch.Tensor:
+    """X ~ N(0,1) bf16 [n_tokens, K], 1 % of channels x10, built in chunks."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    X = torch.empty((n_tokens, K), dtype=torch.bfloat16, device=device)
+    gain = torch.ones(K, dtype=torch.float32, device=device)
+    n_out = max(1, K // 100)
+    idx = torch.randperm(K, generator=g, device=device)[:n_out]
+    gain[idx] = 10.0
+    step = 16384
+    for t0 in range(0, n_tokens, step):
+        t1 = min(n_tokens, t0 + step)
+        X[t0:t1] = (torch.randn((t1 - t0, K), generator=g, device=device) * gain).to(torch.bfloat16)
+    return X
+
+
+def synth_weight(R: int, K: int, seed: int, device) -> torch.Tensor:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return (torch.randn((R, K), generator=g, device=device) * 0.02).to(torch.bfloat16)
+
+
+def quantize_layer(shape, weights, acts, qargs, n_samples):
+    """One step: the hot path over one decoder layer.  Returns the packed outputs."""
+    from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
+
+    outs = []
+    for (gname, K, lins) in shape.groups:
+        acc = HessianAccumulator(K, acts[gname].device)
+        acc.add(acts[gname], num_samples=n_samples)
+        res = gptq_quantize_shared([weights[n] for n, _ in lins], acc, qargs)
+        outs.extend((r.weight_packed, r.weight_scale) for r in res)
+        del acc, res
+    return outs
+
+
+def cpu_baseline_port(seconds_budget: float = 30.0):
+    """The oracle (kind "port") on this box's host cores, on a bounded sample of the same
+    workload: q_proj (4096 x 4096) -- Hessian accumulation in upstream's own form (per-sample
+    fp32 `H += x.T @ x`) for 64 of the 512 samples (extrapolated x8, stated in `sample`), then
+    the LAPACK three-step inverse and the C sweep (OpenMP over rows) in full."""
+    import numpy as np
+
+    from oracle import reference_path as rp
+
+    rp.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    R = K = 4096
+    n_meas = 64
+    rng = np.random.default_rng(2)
+    W = (rng.standard_normal((R, K)) * 0.02).astype(np.float32)
+    H = torch.zeros((K, K), dtype=torch.float32)
+    xs = [torch.from_numpy(rng.standard_normal((SEQ_LEN, K)).astype(np.float32)) for _ in range(8)]
+    t0 = time.perf_counter()
+    n = 0
+    for b in range(n_meas):
+        x = xs[b % 8]
+        H *= n / (n + 1)
+        n += 1
+        x = (2.0 / n) ** 0.5 * x
+        H += x.t() @ x
+    t_hess = (time.perf_counter() - t0) * (N_SAMPLES / n_meas)
+    Hn = H.numpy()
+    t0 = time.perf_counter()
+    out = rp.quantize_weight(W, Hn, actorder="static", inverse="lapack")
+    rp.pack_int4(out["q"])
+    t_rest = time.perf_counter() - t0
+    total = t_hess + t_rest
+    return {
+        "value": R * K / total, "unit": "weights/s", "cores": cores, "kind": "port",
+        "sample": (f"q_proj 4096x4096 W4A16 g128 actorder=static: per-sample fp32 H+=x^T x timed on {n_meas} "
+                   f"of {N_SAMPLES} samples x {SEQ_LEN} tokens and scaled x{N_SAMPLES // n_meas} "
+                   f"({t_hess:.1f} s), + LAPACK inverse, C sweep, pack in full ({t_rest:.1f} s)"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from quantool_amd.engine.model_shapes import MODEL_SHAPES
+    from quantool_amd.engine.schemes import QuantArgs
+    from quantool_amd.hip import _lib
+
+    lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
+    shape = MODEL_SHAPES[MODEL]
+    n_tokens = args.samples * SEQ_LEN
+    qargs = QuantArgs(num_bits=4, symmetric=True, group_size=128, actorder="static")
+
+    weights, acts = {}, {}
+    for gi, (gname, K, lins) in enumerate(shape.groups):
+        acts[gname] = synth_activations(n_tokens, K, seed=2 + 17 * gi + 1000 * rank, device=dev)
+        for li, (lname, R) in enumerate(lins):
+            weights[lname] = synth_weight(R, K, seed=100 * gi + li + 1000 * rank, device=dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        quantize_layer(shape, weights, acts, qargs, args.samples)
+    barrier()
+
+    lib.qt_profile_enable(1)
+    kept = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kept.append(quantize_layer(shape, weights, acts, qargs, args.samples))
+    if dist is not None:
+        # final gather of the packed state to rank 0 (the job's only collective)
+        for outs in kept:
+            for packed, scale in outs:
+                for t in (packed, scale.view(torch.int16)):
+                    gl = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+                    dist.gather(t, gl, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot_ms = ctypes.c_double()
+    launches = ctypes.c_int64()
+    lib.qt_profile_read(_lib_const("QT_PROF_XTX"), ctypes.byref(tot_ms), ctypes.byref(launches))
+    lib.qt_profile_enable(0)
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    weights_done = shape.weights_per_layer * args.steps * world
+    value = weights_done / elapsed
+
+    # roofline of the dominant kernel (xtx_kernel): algorithmic flops N*K*(K+1) per Hessian
+    # (symmetric minimum) / device time of the kernel from HIP events on its stream
+    alg_flops = sum(n_tokens * K * (K + 1) for _, K, _ in shape.groups) * args.steps
+    alg_bytes = sum(n_tokens * K * 2 + K * K * 4 for _, K, _ in shape.groups) * args.steps
+    achieved_tflops = alg_flops / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
+    roofline = {
+        "kernel": "xtx_kernel", "bound": "mfma", "achieved": round(achieved_tflops, 2),
+        "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
+        "traffic": None,
+        "launches": int(launches.value), "avg_launch_ms": round(tot_ms.value / max(1, launches.value), 4),
+        "share_of_step_time": round(tot_ms.value * 1e-3 / elapsed, 4),
+        "hbm_GBps_algorithmic": round(alg_bytes / (tot_ms.value * 1e-3) / 1e9, 1) if tot_ms.value > 0 else 0.0,
+        "note": ("flop-weighted over the 4 Gram launches per step (3x K=4096, 1x K=14336); north_star's HBM "
+                 "figure reported as hbm_GBps_algorithmic; X^T X is MFMA-bound (SURVEY 8d)"),
+    }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_port()
+
+    if rank == 0:
+        line = {
+            "metric": "quantized weights/sec (GPTQ int4, Llama-3-8B, 512 calib samples)",
+            "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder=static, "
+                             "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
+                             "1 decoder layer (7 Linears, 218103808 weights) per step per GPU"),
+                "n_calibration_samples": args.samples, "seq_len": SEQ_LEN,
+                "layers_per_step_per_gpu": 1, "sharding": f"layers over {world} rank(s), RCCL gather of packed state",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _lib_const(name: str) -> int:
+    return {"QT_PROF_XTX": 0, "QT_PROF_SWEEP_BLOCK": 1}[name]
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,14 @@ int qt_dequantize(const int8_t* Qt, int R, int K, const int32_t* col_src, const 
                   const float* zp, int G, const int32_t* g_of_col, void* out, int out_dtype,
                   int64_t ldo, qt_stream_t stream);
 
+/* ---- measurement aid (bench.py roofline leg; not part of the reference surface) -------------
+ * When enabled, HIP events are recorded on the launch stream immediately around the named
+ * kernel; qt_profile_read synchronises them, returns the summed device time and the launch
+ * count since the last read, and resets the slot. */
+enum qt_prof_kernel { QT_PROF_XTX = 0, QT_PROF_SWEEP_BLOCK = 1, QT_PROF_NUM_KERNELS = 2 };
+int qt_profile_enable(int on);
+int qt_profile_read(int kernel_id, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,16 @@ __global__ __launch_bounds__(256) void flat_reverse_lower_to_upper_kernel(float*
     }
 }
 
+// Upstream's LinAlgError fallback, applied on the device so the host need not synchronise:
+// if the factorisation hit a non-positive pivot, U = I (plain round-to-nearest).
+__global__ __launch_bounds__(256) void identity_if_failed_kernel(float* __restrict__ U, int K,
+                                                                 const int32_t* __restrict__ info) {
+    if (*info == 0) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < K) U[(size_t)i * K + j] = (i == j) ? 1.0f : 0.0f;
+}
+
 }  // namespace
 
 extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
@@ -188,6 +198,9 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         if (rc) return rc;
     }
     hipLaunchKernelGGL(flat_reverse_lower_to_upper_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, U, K);
+    QT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(identity_if_failed_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, U, K,
+                       (const int32_t*)info);
     QT_LAUNCH_CHECK();
     return QT_OK;
 }

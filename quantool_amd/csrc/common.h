@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define QT_GLOBAL __attribute__((address_space(1)))
 
 void qt_set_error(const char* fmt, ...);
+void qt_prof_mark(int kernel_id, hipStream_t stream);  // no-op unless qt_profile_enable(1)
 
 #define QT_CHECK_ARG(cond, ...)         \
     do {                                \

@@ -182,8 +182,10 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
     for (int i1 = 0; i1 < K; i1 += BS) {
         const int i2 = (i1 + BS < K) ? i1 + BS : K;
         const int cnt = i2 - i1;
+        qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
         hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R, K, U,
                            scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, ErrT, loss);
+        qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
         QT_LAUNCH_CHECK();
         if (i2 < K) {
             SgemmArgs g;

@@ -269,7 +269,9 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     p.n_tiles = pl.n_tiles;
     p.n_splits = pl.n_splits;
     p.slabs = slabs;
+    qt_prof_mark(QT_PROF_XTX, stream);
     hipLaunchKernelGGL(xtx_kernel, dim3(pl.n_tiles * pl.n_splits), dim3(NTHREADS), LDS_BYTES, stream, p);
+    qt_prof_mark(QT_PROF_XTX, stream);
     QT_LAUNCH_CHECK();
     hipLaunchKernelGGL(xtx_reduce_kernel, dim3(pl.n_tiles, 16), dim3(256), 0, stream, slabs, pl.n_tiles,
                        pl.n_splits, G, K);

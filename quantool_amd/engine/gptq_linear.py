@@ -1,0 +1,187 @@
+"""Per-Linear GPTQ on the device: Hessian accumulation -> prepare -> factorise -> sweep -> pack.
+
+Host-side counterpart of upstream's ``accumulate_hessian`` / ``quantize_weight`` (SURVEY.md
+section 8a rows a7-a11, a14), which quantool reaches through
+``src/quantool/methods/llm_compressor/base.py:161``.  All arithmetic runs in the HIP library
+(``quantool_amd.hip.ops``); torch supplies buffers, the stream and index bookkeeping.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from ..hip import ops
+from .schemes import QuantArgs
+
+
+class HessianAccumulator:
+    """Raw Gram sum G = sum_b X_b^T X_b (fp32, lower triangle) and the sample count n.
+
+    Upstream keeps the running average ``H = H*n/(n+B) ...; H += (2/n) X^T X`` per Linear
+    (a7); ``(2/n) * G`` is the same matrix and the factor is applied in ``hessian_prepare``.
+    Linears that read the same input (q/k/v, gate/up) share one accumulator: their upstream
+    Hessians are byte-identical, so one X^T X pass and one factorisation serve them all.
+    """
+
+    def __init__(self, K: int, device):
+        self.K = K
+        self.G = torch.zeros((K, K), dtype=torch.float32, device=device)
+        self.n = 0
+
+    def add(self, X: torch.Tensor, num_samples: Optional[int] = None) -> None:
+        """X: [B, T, K] or [T, K] in bf16.  ``num_samples`` defaults to B (upstream's num_added)."""
+        if X.dtype != torch.bfloat16:
+            X = X.to(torch.bfloat16)
+        if num_samples is None:
+            num_samples = X.shape[0] if X.dim() == 3 else 1
+        ops.xtx_accumulate(X, self.G)
+        self.n += int(num_samples)
+
+    def reset(self) -> None:
+        self.G.zero_()
+        self.n = 0
+
+
+@dataclass
+class GPTQResult:
+    """Outputs for one Linear, named as the compressed-tensors state_dict names them (a14)."""
+    weight_packed: Optional[torch.Tensor]       # int32 [R, ceil(K/8)] (4-bit) or None
+    weight_q: Optional[torch.Tensor]            # int8 levels [R, K] when not 4-bit packed
+    weight_scale: torch.Tensor                  # model dtype [R, G]
+    weight_zero_point: Optional[torch.Tensor]   # int8 [R, G] (asymmetric only)
+    weight_g_idx: Optional[torch.Tensor]        # int32 [K] (actorder == "group" only)
+    weight_shape: torch.Tensor                  # int64 [2]
+    loss: torch.Tensor                          # fp32 [R] per-row loss (upstream logs its sum)
+    info: torch.Tensor                          # int32 [1]; != 0 -> Hessian not PD, U = I used
+    scale_f32: torch.Tensor = field(repr=False, default=None)
+    zp_f32: torch.Tensor = field(repr=False, default=None)
+    Qt: torch.Tensor = field(repr=False, default=None)          # int8 [K, R] sweep order
+    col_src: Optional[torch.Tensor] = field(repr=False, default=None)
+    g_of_col: torch.Tensor = field(repr=False, default=None)    # int32 [K] group of original col
+
+    def dequantized(self, dtype=torch.float32) -> torch.Tensor:
+        """(q - zp) * scale in original column order -- what upstream writes back to the module."""
+        return ops.dequantize(self.Qt, self.scale_f32, self.zp_f32, self.g_of_col, self.col_src, dtype)
+
+
+def _normalize_actorder(actorder) -> Optional[str]:
+    if actorder is None or actorder is False:
+        return None
+    a = str(actorder).lower()
+    if a in ("static", "weight"):
+        return "static"
+    if a == "group":
+        return "group"
+    if a in ("none", "false"):
+        return None
+    raise ValueError(f"unknown actorder {actorder!r} (expected None, 'static'/'weight' or 'group')")
+
+
+def gptq_quantize_shared(weights: Sequence[torch.Tensor], acc: HessianAccumulator, qargs: QuantArgs, *,
+                         block_size: int = 128, dampening_frac: float = 0.01,
+                         scale_dtype: Optional[torch.dtype] = None,
+                         keep: Optional[dict] = None) -> List[GPTQResult]:
+    """Quantise every ``weights[i]`` ([R_i, K], bf16 or fp32) that shares the input behind ``acc``.
+
+    Follows upstream's ``quantize_weight`` order: observer, optional activation
+    ordering, dead columns, damping, factorisation, block sweep; the rows of all weights are
+    swept as one stacked matrix (rows are independent given U).
+    """
+    if acc.n <= 0:
+        raise ValueError("no calibration samples were accumulated for this Linear")
+    K = acc.K
+    dev = acc.G.device
+    actorder = _normalize_actorder(qargs.actorder)
+    gs = qargs.kernel_group_size
+    gsz = K if gs <= 0 else gs
+    if K % gsz:
+        raise ValueError(f"in_features {K} not divisible by group_size {gsz}")
+    G = K // gsz
+    for w in weights:
+        if w.dim() != 2 or w.shape[1] != K:
+            raise ValueError(f"weight shape {tuple(w.shape)} does not match in_features {K}")
+    rows = [int(w.shape[0]) for w in weights]
+    R = sum(rows)
+
+    # ---- activation ordering (a9): perm = argsort(diag H, descending) --------------------
+    perm = inv = None
+    if actorder is not None:
+        diag = ops.hessian_diag(acc.G, acc.n)
+        perm = torch.argsort(diag, descending=True, stable=True).to(torch.int32)
+        inv = torch.empty_like(perm)
+        inv[perm.long()] = torch.arange(K, dtype=torch.int32, device=dev)
+    ar = torch.arange(K, dtype=torch.int32, device=dev)
+    g_orig = (ar // gsz).to(torch.int32)
+
+    # ---- prepare + factorise once for all sharers (a8) -----------------------------------
+    A, dead, _ = ops.hessian_prepare(acc.G, acc.n, dampening_frac, perm)
+    U, info = ops.cholesky_inverse_upper(A)
+    del A
+
+    # ---- stacked fp32 working copy in sweep order, observer (a10) ------------------------
+    Wf = torch.empty((R, K), dtype=torch.float32, device=dev)
+    scale = torch.empty((R, G), dtype=torch.float32, device=dev)
+    zp = torch.empty((R, G), dtype=torch.float32, device=dev)
+    scale_t = torch.empty((G, R), dtype=torch.float32, device=dev)
+    zp_t = torch.empty((G, R), dtype=torch.float32, device=dev)
+    r0 = 0
+    for w, r in zip(weights, rows):
+        if w.stride(1) != 1:
+            w = w.contiguous()
+        ops.weight_gather_f32(w, perm, dead, out=Wf[r0:r0 + r])
+        r0 += r
+    if actorder == "group":
+        # qparams on the permuted matrix; groups are runs of 128 sweep positions
+        s_, z_, st_, zt_ = ops.group_minmax_qparams(Wf, gs, qargs.symmetric, qargs.num_bits)
+        scale, zp, scale_t, zp_t = s_, z_, st_, zt_
+        g_sweep = g_orig
+    else:
+        # qparams on the ORIGINAL matrix (before permutation / dead-column zeroing)
+        r0 = 0
+        for w, r in zip(weights, rows):
+            s_, z_, _, _ = ops.group_minmax_qparams(w if w.stride(1) == 1 else w.contiguous(), gs,
+                                                    qargs.symmetric, qargs.num_bits)
+            scale[r0:r0 + r] = s_
+            zp[r0:r0 + r] = z_
+            r0 += r
+        scale_t.copy_(scale.t())
+        zp_t.copy_(zp.t())
+        g_sweep = g_orig if perm is None else g_orig[perm.long()].contiguous()
+
+    # ---- the sweep (a11) ------------------------------------------------------------------
+    if keep is not None:  # stage boundaries for the parity tests
+        keep.update(U=U.clone(), perm=perm, dead=dead)
+    Qt, loss = ops.gptq_sweep(Wf, U, scale_t, zp_t, g_sweep, block_size, qargs.num_bits)
+    del Wf, U
+
+    # ---- outputs in original column order (a14) -------------------------------------------
+    col_src = inv  # output column c lives at sweep position inv[c]
+    if actorder == "group":
+        g_of_col = g_sweep[inv.long()].contiguous()     # upstream's saved weight_g_idx
+    else:
+        g_of_col = g_orig
+    out: List[GPTQResult] = []
+    r0 = 0
+    for w, r in zip(weights, rows):
+        Qt_i = Qt[:, r0:r0 + r].contiguous() if len(rows) > 1 else Qt
+        sdt = scale_dtype or (w.dtype if w.dtype in (torch.bfloat16, torch.float16) else torch.float32)
+        sc_i = scale[r0:r0 + r].contiguous()
+        zp_i = zp[r0:r0 + r].contiguous()
+        packed = ops.pack_int4(Qt_i, col_src) if qargs.num_bits == 4 else None
+        wq = None
+        if packed is None:
+            wq = (Qt_i.t() if col_src is None else Qt_i[col_src.long()].t()).contiguous()
+        out.append(GPTQResult(
+            weight_packed=packed, weight_q=wq, weight_scale=sc_i.to(sdt),
+            weight_zero_point=None if qargs.symmetric else zp_i.to(torch.int8),
+            weight_g_idx=g_of_col if actorder == "group" else None,
+            weight_shape=torch.tensor([r, K], dtype=torch.int64), loss=loss[r0:r0 + r], info=info,
+            scale_f32=sc_i, zp_f32=zp_i, Qt=Qt_i, col_src=col_src, g_of_col=g_of_col))
+        r0 += r
+    return out
+
+
+def gptq_quantize_linear(weight: torch.Tensor, acc: HessianAccumulator, qargs: QuantArgs, **kw) -> GPTQResult:
+    return gptq_quantize_shared([weight], acc, qargs, **kw)[0]

@@ -43,6 +43,8 @@ SIGNATURES = {
     "qt_gptq_sweep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "qt_pack_int4": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "qt_profile_enable": (c_int, [c_int]),
+    "qt_profile_read": (c_int, [c_int, c_void_p, c_void_p]),
     "qt_dequantize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                               c_int, c_int64, c_void_p]),
 }
