@@ -76,6 +76,23 @@ def quantize_layer(shape, weights, acts, qargs, n_samples):
     return outs
 
 
+def host_cores() -> int:
+    """Threads this process may actually use: affinity, capped by the cgroup CPU quota and by the
+    16-core share a one-GPU box grants (more threads than cores only thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("QT_CPU_THREADS", "16"))))
+
+
 def cpu_baseline_port(seconds_budget: float = 30.0):
     """The oracle (kind "port") on this box's host cores, on a bounded sample of the same
     workload: q_proj (4096 x 4096) -- Hessian accumulation in upstream's own form (per-sample
@@ -86,12 +103,9 @@ def cpu_baseline_port(seconds_budget: float = 30.0):
     from oracle import reference_path as rp
 
     rp.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
+    rp.set_num_threads(cores)
     R = K = 4096
     n_meas = 64
     rng = np.random.default_rng(2)

@@ -455,5 +455,9 @@ def channel_minmax(X_bf16):
     return X.min(axis=0), X.max(axis=0)
 
 
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(ctypes.c_int(int(n)))
+
+
 def num_threads() -> int:
     return int(lib().orc_num_threads())
