@@ -20,73 +20,291 @@ namespace {
 constexpr int NB = 128;
 constexpr int LDP = NB + 1;  // padded LDS leading dimension
 
-// One workgroup: Cholesky (upper) of an n x n block (n <= 128) + its triangular inverse.
-//   P      : input block, upper triangle read, row stride ldp
-//   Rout   : receives R (upper triangle written; strict lower untouched), stride ldr
-//   Dinv   : receives R^-1 as a dense 128x128 row-major block (zeros outside the triangle / n)
-//   Ydiag  : receives (R^-1)^T as a dense n x n block (zeros above the diagonal), stride ldy
-//   info   : first non-positive pivot (1-based global index) if any; col0 = global offset
-__global__ __launch_bounds__(256) void potf2_inv_kernel(const float* __restrict__ P, int64_t ldp, int n,
-                                                        float* __restrict__ Rout, int64_t ldr,
-                                                        float* __restrict__ Dinv, float* __restrict__ Ydiag,
-                                                        int64_t ldy, int32_t* info, int col0) {
+// ---- panel kernels --------------------------------------------------------------------------
+// All three keep a 128-long column in REGISTERS.  Registers cannot be indexed at run time, so a
+// column is held as four 32-entry arrays: the 32 steps inside a sub-block are unrolled (static
+// indices) and the sub-block loop stays a run-time loop with wave-uniform guards.
+constexpr int LDT = NB + 4;  // LDS leading dimension with 16-byte aligned rows
+constexpr int RD_STRIDE = NB * NB + 4 * 32 * 32;  // dense R block + four 32x32 sub-block inverses
+
+#define QT_SEL4(kb, v0, v1, v2, v3) ((kb) == 0 ? (v0) : (kb) == 1 ? (v1) : (kb) == 2 ? (v2) : (v3))
+
+// potf2: one workgroup (256 threads), Cholesky (upper, A = R^T R) of an n x n block (n <= 128),
+// blocked by 32 inside the workgroup so that only 4 x 32 steps are sequential and everything
+// else is f32 MFMA on LDS-resident tiles:
+//   for kb = 0..3:
+//     (i)   wave 0: factor the 32x32 diagonal sub-block with one column per lane in registers;
+//           row c reaches the other lanes through v_readlane (no LDS, no barrier), then the
+//           32-step back substitution for X_kb = R_kk^-1 the same way;
+//     (ii)  R[kb, a] = X_kb^T A[kb, a]           for a > kb          (16 MFMAs per 32x32 tile)
+//     (iii) A[a, a'] -= R[kb, a]^T R[kb, a']     for kb < a <= a'
+//   P     : input block, upper triangle read, row stride ldp
+//   Rout  : receives R (upper triangle written; strict lower untouched), stride ldr
+//   Rd    : dense 128x128 row-major copy of R (zeros below the diagonal; identity padding >= n)
+//           followed by D32[4][32][32], D32[b][k][i] = X_b[k][i]
+//   info  : first non-positive pivot (1-based global index) if any; col0 = global offset
+constexpr int LDA = NB + 4;
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// acc (+)= sum_k A[k][i] * B[k][n] over k = 0..31 for one 32x32 tile (TN form, LDS operands)
+__device__ __forceinline__ void mma32_tn(const float* A, int lda, const float* B, int ldb, f32x16& acc,
+                                         int l31, int h, bool negate_a) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        float a = A[(2 * kk + h) * lda + l31];
+        const float b = B[(2 * kk + h) * ldb + l31];
+        if (negate_a) a = -a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void potf2_kernel(const float* __restrict__ P, int64_t ldp, int n,
+                                                    float* __restrict__ Rout, int64_t ldr,
+                                                    float* __restrict__ Rd, int32_t* info, int col0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* a = sm;             // [NB][LDP]  factor
-    float* x = sm + NB * LDP;  // [NB][LDP]  inverse
-    const int tid = threadIdx.x;
+    float* As = sm;                // [NB][LDA]
+    float* Xs = sm + NB * LDA;     // [4][32][32]  Xs[b][k][i] = X_b[k][i]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
 
     for (int e = tid; e < NB * NB; e += 256) {
         const int i = e / NB, j = e % NB;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
         float v = (i == j) ? 1.0f : 0.0f;
-        if (i < n && j < n && j >= i) v = P[(size_t)i * ldp + j];
-        a[i * LDP + j] = v;
-        x[i * LDP + j] = 0.0f;
+        if (hi < n) v = P[(size_t)lo * ldp + hi];  // symmetric fill from the upper triangle
+        As[i * LDA + j] = v;
     }
     __syncthreads();
 
-    const int jcol = tid & (NB - 1), half = tid >> 7;
-    for (int c = 0; c < n; ++c) {
-        float piv = a[c * LDP + c];
-        if (!(piv > 0.0f)) {  // uniform branch (all threads read the same pivot)
-            if (tid == 0) atomicCAS(info, 0, col0 + c + 1);
-            piv = 1.0f;
+    int bad = 0;
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) {
+        float* Akk = As + (32 * kb) * LDA + 32 * kb;
+        // ---- (i) diagonal sub-block: factor + inverse, wave 0, lanes 0..31 = columns ----
+        if (wave == 0) {
+            float col[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) col[i] = Akk[i * LDA + l31];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                float piv = readlane_f(col[c], c);
+                const bool isbad = !(piv > 0.0f);
+                bad = (isbad && bad == 0 && 32 * kb + c < n) ? 32 * kb + c + 1 : bad;
+                piv = isbad ? 1.0f : piv;
+                const float rs = __builtin_amdgcn_rsqf(piv);
+                const float rcj = col[c] * rs;           // R[c][j] on lane j (j >= c meaningful)
+                col[c] = rcj;
+#pragma unroll
+                for (int i = c + 1; i < 32; ++i) {
+                    const float rci = readlane_f(rcj, i);
+                    col[i] = fmaf(-rci, rcj, col[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // X = R_kk^-1: lane j owns column j of X; column p of R lives on lane p
+            float x[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) x[i] = (i == l31) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int p = 31; p >= 0; --p) {
+                const float rpp = readlane_f(col[p], p);
+                float rinv = __builtin_amdgcn_rcpf(rpp);
+                rinv = fmaf(fmaf(-rpp, rinv, 1.0f), rinv, rinv);
+                const float xp = x[p] * rinv;
+                x[p] = xp;
+#pragma unroll
+                for (int i = 0; i < p; ++i) {
+                    const float rip = readlane_f(col[i], p);
+                    x[i] = fmaf(-rip, xp, x[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane < 32) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    Akk[i * LDA + l31] = (i <= l31) ? col[i] : 0.0f;    // R_kk, zeros below diagonal
+                    Xs[(kb * 32 + i) * 32 + l31] = (i <= l31) ? x[i] : 0.0f;
+                }
+            }
         }
-        const float d = sqrtf(piv);
         __syncthreads();
-        if (tid < NB) {
-            if (tid == c) a[c * LDP + c] = d;
-            else if (tid > c) a[c * LDP + tid] = a[c * LDP + tid] / d;
+        if (kb == 3) break;
+        // ---- (ii) R[kb, a] = X_kb^T A[kb, a], a > kb: one tile per wave (round robin) ----
+        for (int a = kb + 1 + wave; a < 4; a += 4) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            float* Bt = As + (32 * kb) * LDA + 32 * a;
+            mma32_tn(Xs + kb * 1024, 32, Bt, LDA, acc, l31, h, false);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Bt[((r & 3) + 8 * (r >> 2) + 4 * h) * LDA + l31] = acc[r];
         }
         __syncthreads();
-        // trailing update of the upper triangle: a[i][j] -= a[c][i] * a[c][j], c < i <= j
-        if (jcol > c) {
-            const float rcj = a[c * LDP + jcol];
-            for (int i = c + 1 + half; i <= jcol; i += 2) a[i * LDP + jcol] -= a[c * LDP + i] * rcj;
+        // ---- (iii) A[a, a'] -= R[kb, a]^T R[kb, a'], kb < a <= a' ----
+        {
+            int t = 0;
+            for (int a = kb + 1; a < 4; ++a)
+                for (int a2 = a; a2 < 4; ++a2, ++t) {
+                    if ((t & 3) != wave) continue;
+                    float* Ct = As + (32 * a) * LDA + 32 * a2;
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = Ct[((r & 3) + 8 * (r >> 2) + 4 * h) * LDA + l31];
+                    mma32_tn(As + (32 * kb) * LDA + 32 * a, LDA, As + (32 * kb) * LDA + 32 * a2, LDA, acc, l31, h,
+                             true);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Ct[((r & 3) + 8 * (r >> 2) + 4 * h) * LDA + l31] = acc[r];
+                }
         }
-        // the loop-top barrier of the next step orders these writes before the pivot read
         __syncthreads();
     }
+    if (bad != 0 && tid == 0) atomicCAS(info, 0, col0 + bad);
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, jj = e % NB;
+        const float v = (jj >= i) ? As[i * LDA + jj] : 0.0f;
+        if (i < n && jj < n && jj >= i) Rout[(size_t)i * ldr + jj] = v;
+        Rd[e] = v;
+    }
+    for (int e = tid; e < 4 * 32 * 32; e += 256) Rd[NB * NB + e] = Xs[e];
+}
 
-    // X = R^-1 (upper) by back substitution, one thread per column j.
-    if (tid < NB) {
-        const int j = tid;
-        x[j * LDP + j] = 1.0f / a[j * LDP + j];
-        for (int i = NB - 2; i >= 0; --i) {
-            if (i < j) {
-                float s = 0.0f;
-                for (int pidx = i + 1; pidx <= j; ++pidx) s = fmaf(a[i * LDP + pidx], x[pidx * LDP + j], s);
-                x[i * LDP + j] = -s / a[i * LDP + i];
+// trsm: Z = R^-T B for a 128 x ncols panel on the f32 MFMA, by BLOCKED forward substitution
+// with the 32x32 inverses X_b of R's diagonal sub-blocks (no divisions, no 128-long chain):
+//     Z_b = X_b^T B_b ;   B_a -= R[b, a]^T Z_b   for a > b            (b = 0..3)
+// Each wave owns 32 columns and keeps its four 32x32 row-block tiles in accumulators.  A result
+// tile feeds the next MFMA directly as its B operand (accumulator register r holds row
+// rho(r) = (r&3) + 8*(r>>2) on lanes 0-31 and rho(r)+4 on lanes 32-63, which is just a pairing
+// of the k indices: the k order of these sums is free), so Z never round-trips through LDS;
+// only the A operands (X_b, -R[b,a], k-major as stored) are read from LDS, one b32 per MFMA.
+//   Rd : dense 128x128 R followed by D32[4][32][32], D32[b][k][i] = X_b[k][i] (potf2_kernel)
+__global__ __launch_bounds__(256) void trsm_rt_kernel(const float* __restrict__ Rd, int n,
+                                                      const float* __restrict__ B, int64_t ldb,
+                                                      float* __restrict__ Z, int64_t ldz, int ncols) {
+    extern __shared__ __attribute__((aligned(16))) float Rs[];  // [RD_STRIDE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < RD_STRIDE / 4; e += 256) ((f32x4*)Rs)[e] = ((const f32x4*)Rd)[e];
+    const float* D32 = Rs + NB * NB;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int col = blockIdx.x * 128 + wave * 32 + l31;
+    const bool cok = col < ncols;
+    const int colc = cok ? col : ncols - 1;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+            acc[a][r] = (row < n) ? B[(size_t)row * ldb + colc] : 0.0f;
+        }
+    __syncthreads();
+
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        // Z_b[i][col] = sum_k X_b[k][i] * B_b[k][col]
+        f32x16 zb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zb[r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float av = D32[(b * 32 + k) * 32 + l31];  // X_b[k][i = l31]
+            zb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc[b][r], zb, 0, 0, 0);
+        }
+        acc[b] = zb;
+#pragma unroll
+        for (int a = b + 1; a < 4; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float av = -Rs[(32 * b + k) * NB + 32 * a + l31];  // -R[32b+k][32a+i]
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, zb[r], acc[a], 0, 0, 0);
             }
         }
     }
-    __syncthreads();
+    if (cok) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < n) Z[(size_t)row * ldz + col] = acc[a][r];
+            }
+    }
+}
 
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        const bool in = (i < n && j < n);
-        if (in && j >= i) Rout[(size_t)i * ldr + j] = a[i * LDP + j];
-        Dinv[e] = (in && j >= i) ? x[i * LDP + j] : 0.0f;
-        if (in) Ydiag[(size_t)i * ldy + j] = (j <= i) ? x[j * LDP + i] : 0.0f;
+// Batched inverse of the diagonal blocks (one workgroup per block, off the factorisation's
+// critical path): X = R^-1, thread j < 128 owns column j (x = e_j) and runs the column-oriented
+// back substitution p = 127..0: x_p /= R_pp; x_i -= R_ip x_p (i < p), reading column p of R as a
+// contiguous row of the transposed LDS copy.
+//   Dinv[b]  : R^-1 dense 128x128 row-major (zeros outside the triangle / n)
+//   Ydiag(b) : (R^-1)^T dense n x n at Y + (b*128)*(ldy+1) (zeros above the diagonal)
+__global__ __launch_bounds__(128) void trinv_batched_kernel(const float* __restrict__ Rd_all, int K,
+                                                            float* __restrict__ Dinv_all,
+                                                            float* __restrict__ Y, int64_t ldy) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Rt = sm;             // [NB][LDT]  Rt[p][i] = R[i][p]
+    float* Xs = sm + NB * LDT;  // [NB][LDP]
+    const int b = blockIdx.x;
+    const int n = (K - b * NB < NB) ? K - b * NB : NB;
+    const float* Rd = Rd_all + (size_t)b * RD_STRIDE;
+    const int j = threadIdx.x;
+    for (int e = j; e < NB * NB; e += NB) {
+        const int i = e / NB, c = e % NB;
+        Rt[c * LDT + i] = Rd[e];
+    }
+    __syncthreads();
+    float x0[32], x1[32], x2[32], x3[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        x0[r] = (r == j) ? 1.0f : 0.0f;
+        x1[r] = (32 + r == j) ? 1.0f : 0.0f;
+        x2[r] = (64 + r == j) ? 1.0f : 0.0f;
+        x3[r] = (96 + r == j) ? 1.0f : 0.0f;
+    }
+#pragma unroll 1
+    for (int pb = 3; pb >= 0; --pb) {
+#pragma unroll
+        for (int pp = 31; pp >= 0; --pp) {
+            const int p = 32 * pb + pp;
+            const float* rp = Rt + p * LDT;  // rp[i] = R[i][p]
+            const float xp = QT_SEL4(pb, x0[pp], x1[pp], x2[pp], x3[pp]) / rp[p];
+            if (pb == 0) x0[pp] = xp;
+            if (pb == 1) x1[pp] = xp;
+            if (pb == 2) x2[pp] = xp;
+            if (pb == 3) x3[pp] = xp;
+#define QT_XUPD(arr, a, r_to)                                                 \
+    _Pragma("unroll") for (int r4 = 0; r4 < (r_to); r4 += 4) {                 \
+        const f32x4 v4 = *(const f32x4*)(rp + 32 * (a) + r4);                 \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                         \
+            if (r4 + e < (r_to)) arr[r4 + e] = fmaf(-v4[e], xp, arr[r4 + e]); \
+    }
+            if (pb == 0) { QT_XUPD(x0, 0, pp) } else { QT_XUPD(x0, 0, 32) }
+            if (pb == 1) { QT_XUPD(x1, 1, pp) } else if (pb > 1) { QT_XUPD(x1, 1, 32) }
+            if (pb == 2) { QT_XUPD(x2, 2, pp) } else if (pb > 2) { QT_XUPD(x2, 2, 32) }
+            if (pb == 3) { QT_XUPD(x3, 3, pp) }
+#undef QT_XUPD
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        Xs[r * LDP + j] = x0[r];
+        Xs[(32 + r) * LDP + j] = x1[r];
+        Xs[(64 + r) * LDP + j] = x2[r];
+        Xs[(96 + r) * LDP + j] = x3[r];
+    }
+    __syncthreads();
+    float* Dinv = Dinv_all + (size_t)b * NB * NB;
+    float* Yd = Y + (size_t)(b * NB) * ldy + b * NB;
+    for (int e = j; e < NB * NB; e += NB) {
+        const int i = e / NB, jj = e % NB;
+        const bool in = (i < n && jj < n);
+        Dinv[e] = (in && jj >= i) ? Xs[i * LDP + jj] : 0.0f;
+        if (in) Yd[(size_t)i * ldy + jj] = (jj <= i) ? Xs[jj * LDP + i] : 0.0f;
     }
 }
 
@@ -125,8 +343,8 @@ __global__ __launch_bounds__(256) void identity_if_failed_kernel(float* __restri
 extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
     if (K <= 0) return 0;
     const size_t nb = (K + NB - 1) / NB;
-    // P panel [128, K] + T panel [128, K] + Dinv [nb][128*128]
-    return 2 * (size_t)NB * K * 4 + nb * NB * NB * 4 + 256;
+    // P panel [128, K] + T panel [128, K] + Rd, Dinv [nb][128*128] each + split-K slabs
+    return 2 * (size_t)NB * K * 4 + nb * (NB * NB + RD_STRIDE) * 4 + (size_t)16 * NB * K * 4 + 256;
 }
 
 extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
@@ -138,21 +356,30 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         qt_set_error("qt_cholesky_inverse_upper: workspace %zu < required %zu", workspace_bytes, need);
         return QT_ERR_WORKSPACE;
     }
+    const int nblk = (K + NB - 1) / NB;
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
     float* P = (float*)ws;
     float* T = P + (size_t)NB * K;
-    float* Dinv = T + (size_t)NB * K;
+    float* Rd = T + (size_t)NB * K;
+    float* Dinv = Rd + (size_t)nblk * RD_STRIDE;
+    float* split_ws = Dinv + (size_t)nblk * NB * NB;
+    const size_t split_ws_bytes = (size_t)16 * NB * K * 4;
     float* Y = U;
-    const int nblk = (K + NB - 1) / NB;
-    const size_t panel_lds = 2 * NB * LDP * sizeof(float);
+    const size_t inv_lds = (size_t)(NB * LDT + NB * LDP) * sizeof(float);
+    const size_t potf2_lds = (size_t)(NB * LDA + 4 * 32 * 32) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        QT_HIP(hipFuncSetAttribute((const void*)potf2_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)panel_lds));
+        QT_HIP(hipFuncSetAttribute((const void*)potf2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)potf2_lds));
+        QT_HIP(hipFuncSetAttribute((const void*)trsm_rt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(RD_STRIDE * sizeof(float))));
+        QT_HIP(hipFuncSetAttribute((const void*)trinv_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)inv_lds));
         attr_set = true;
     }
     QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), stream));
 
+    // ---- A = R^T R, left-looking by block rows ----
     for (int j = 0; j < nblk; ++j) {
         const int j0 = j * NB, nbj = (K - j0 < NB) ? K - j0 : NB;
         SgemmArgs g;
@@ -161,23 +388,25 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         g.Cin = A + (size_t)j0 * K + j0; g.ldcin = K;
         g.Cout = P; g.ldcout = K;
         g.M = nbj; g.N = K - j0; g.kdim = j0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+        g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
         int rc = qt_sgemm_tn(g, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), panel_lds, stream, (const float*)P, (int64_t)K,
-                           nbj, A + (size_t)j0 * K + j0, (int64_t)K, Dinv + (size_t)j * NB * NB,
-                           Y + (size_t)j0 * K + j0, (int64_t)K, info, j0);
+        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), potf2_lds, stream, (const float*)P, (int64_t)K, nbj,
+                           A + (size_t)j0 * K + j0, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0);
         QT_LAUNCH_CHECK();
-        if (j0 + nbj < K) {
-            SgemmArgs t;
-            t.A = Dinv + (size_t)j * NB * NB; t.lda = NB;
-            t.B = P + nbj; t.ldb = K;
-            t.Cin = nullptr; t.ldcin = 0;
-            t.Cout = A + (size_t)j0 * K + j0 + nbj; t.ldcout = K;
-            t.M = nbj; t.N = K - j0 - nbj; t.kdim = nbj; t.k_mode = SG_K_FULL; t.mode = SG_MODE_SET;
-            rc = qt_sgemm_tn(t, stream);
-            if (rc) return rc;
+        const int rest = K - j0 - nbj;
+        if (rest > 0) {
+            hipLaunchKernelGGL(trsm_rt_kernel, dim3((rest + 127) / 128), dim3(256), RD_STRIDE * sizeof(float), stream,
+                               (const float*)(Rd + (size_t)j * RD_STRIDE), nbj, (const float*)(P + nbj), (int64_t)K,
+                               A + (size_t)j0 * K + j0 + nbj, (int64_t)K, rest);
+            QT_LAUNCH_CHECK();
         }
     }
+    // ---- all diagonal-block inverses at once ----
+    hipLaunchKernelGGL(trinv_batched_kernel, dim3(nblk), dim3(NB), inv_lds, stream, (const float*)Rd, K, Dinv, Y,
+                       (int64_t)K);
+    QT_LAUNCH_CHECK();
+    // ---- Y = R^-T by block rows ----
     for (int i = 1; i < nblk; ++i) {
         const int i0 = i * NB, nbi = (K - i0 < NB) ? K - i0 : NB;
         SgemmArgs g;
@@ -186,6 +415,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         g.Cin = nullptr; g.ldcin = 0;
         g.Cout = T; g.ldcout = K;
         g.M = nbi; g.N = i0; g.kdim = i0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
+        g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
         int rc = qt_sgemm_tn(g, stream);
         if (rc) return rc;
         SgemmArgs t;

@@ -19,6 +19,13 @@ struct SgemmArgs {
     int M, N, kdim;
     int k_mode;
     int mode;
+    // split-K (optional): when split_ws != nullptr and the shape is latency-bound (few tiles,
+    // long k), partial products go to slabs in split_ws and an ordered reduction applies `mode`.
+    // Never used when bit-exact k order matters (the caller passes nullptr there).
+    float* split_ws = nullptr;
+    size_t split_ws_bytes = 0;
+    // internal (set by qt_sgemm_tn)
+    int k_chunk = 0;
 };
 
 // Enqueue on `stream`; picks the tile size from the problem shape.  Returns qt_status.

@@ -10,7 +10,7 @@ constexpr int BK = 16;
 constexpr int NT = 256;
 
 template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {
+__global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {  // p is modified per z-slice
     constexpr int WM = BM / 64, WN = BN / 64;  // 32x32 sub-tiles per wave in m / n
     constexpr int A4 = BK * BM / 4 / NT;       // float4 loads per thread for A
     constexpr int B4 = BK * BN / 4 / NT;
@@ -24,7 +24,13 @@ __global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {
 
     int k_begin = 0;
     if (p.k_mode == SG_K_FROM_N0) k_begin = n0 / BK * BK;
-    const int k_end = p.kdim;
+    int k_end = p.kdim;
+    if (p.k_chunk > 0) {  // split-K: this z-slice owns [z*k_chunk, (z+1)*k_chunk)
+        const int lo = blockIdx.z * p.k_chunk, hi = lo + p.k_chunk;
+        k_begin = k_begin > lo ? k_begin : lo;
+        k_end = k_end < hi ? k_end : hi;
+        p.Cout += (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N;
+    }
 
     const bool a_vec = (p.lda % 4 == 0) && (((uintptr_t)p.A & 15) == 0);
     const bool b_vec = (p.ldb % 4 == 0) && (((uintptr_t)p.B & 15) == 0);
@@ -134,9 +140,38 @@ __global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {
             }
 }
 
+// Cout = mode(Cin, sum_z slab[z]) in ascending z (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int M,
+                                                            int N, const float* __restrict__ Cin, int64_t ldcin,
+                                                            float* __restrict__ Cout, int64_t ldcout, int mode) {
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int row = blockIdx.y;
+    if (col >= N) return;
+    const size_t mn = (size_t)M * N;
+    if (col + 3 < N && (N & 3) == 0) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splits; ++z) s += *(const f32x4*)(slabs + z * mn + (size_t)row * N + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = s[e];
+            if (mode == SG_MODE_SUB) v = Cin[(size_t)row * ldcin + col + e] - v;
+            if (mode == SG_MODE_NEG) v = -v;
+            Cout[(size_t)row * ldcout + col + e] = v;
+        }
+    } else {
+        for (int e = 0; e < 4 && col + e < N; ++e) {
+            float v = 0.f;
+            for (int z = 0; z < splits; ++z) v += slabs[z * mn + (size_t)row * N + col + e];
+            if (mode == SG_MODE_SUB) v = Cin[(size_t)row * ldcin + col + e] - v;
+            if (mode == SG_MODE_NEG) v = -v;
+            Cout[(size_t)row * ldcout + col + e] = v;
+        }
+    }
+}
+
 template <int BM, int BN>
-int launch(const SgemmArgs& a, hipStream_t stream) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
+int launch(const SgemmArgs& a, hipStream_t stream, int splits = 1) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     switch (a.mode) {
         case SG_MODE_SUB:
             hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB>), grid, dim3(NT), 0, stream, a);
@@ -156,8 +191,34 @@ int launch(const SgemmArgs& a, hipStream_t stream) {
 
 int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return QT_OK;
-    const long big_tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    // fewer than ~1.5 rounds of 128x128 tiles on 256 CUs: use 64x64 tiles for 4x the workgroups
-    if (big_tiles >= 384) return launch<128, 128>(a, stream);
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    // Latency-bound shape (fewer 128x128 tiles than CUs, long k): keep the MFMA-dense 128x128
+    // tile and split k over workgroups to fill the chip; slabs are reduced in ascending order.
+    if (a.split_ws && t128 < 192 && a.kdim >= 512) {
+        int splits = (int)(256 / t128);
+        if (splits > 16) splits = 16;
+        int chunk = (a.kdim + splits - 1) / splits;
+        chunk = (chunk + 63) / 64 * 64;  // whole BK steps
+        if (chunk < 256) chunk = 256;
+        splits = (a.kdim + chunk - 1) / chunk;
+        const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
+        if (splits >= 2 && need <= a.split_ws_bytes) {
+            SgemmArgs part = a;
+            part.Cin = nullptr;
+            part.ldcin = 0;
+            part.Cout = a.split_ws;
+            part.ldcout = a.N;
+            part.mode = SG_MODE_SET;
+            part.k_chunk = chunk;
+            const int rc = launch<128, 128>(part, stream, splits);
+            if (rc) return rc;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.N / 4 + 255) / 256 + 1, a.M), dim3(256), 0, stream,
+                               (const float*)a.split_ws, splits, a.M, a.N, a.Cin, a.ldcin, a.Cout, a.ldcout, a.mode);
+            QT_LAUNCH_CHECK();
+            return QT_OK;
+        }
+    }
+    // enough 128x128 tiles for ~1.5 rounds on 256 CUs, else 64x64 tiles for 4x the workgroups
+    if (t128 >= 384) return launch<128, 128>(a, stream);
     return launch<64, 64>(a, stream);
 }
