@@ -1,0 +1,168 @@
+"""``oneshot``: the single call quantool's llm-compressor plugins make
+(``self.last_model = oneshot_fn(**oneshot_kwargs)``, ``src/quantool/methods/llm_compressor/base.py:161``),
+re-provided on top of the HIP per-Linear path.
+
+Accepted ``model`` values
+  * ``LinearCalibrationSet`` -- explicit (activations, weights) groups: the per-Linear mode the
+    benchmarks and parity tests use (BASELINE.md 2.2 "per-linear microbenchmark");
+  * a ``torch.nn.Module`` (or a local directory loadable with ``transformers``) -- the sequential
+    decoder-layer pipeline (``engine.sequential``).
+
+Returns an object with ``save_pretrained(dest, save_compressed=True)`` like the model upstream
+returns (``base.py:188``).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from .gptq_linear import GPTQResult, HessianAccumulator, gptq_quantize_shared
+from .modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class LinearGroup:
+    """Linears that read the same activation.  ``activations``: tensor [S, T, K] / [N, K] (bf16) or
+    an iterable of such batches; ``weights``: name -> [R, K] tensor."""
+    name: str
+    activations: Any
+    weights: Dict[str, torch.Tensor]
+    num_samples: Optional[int] = None
+
+
+@dataclass
+class LinearCalibrationSet:
+    groups: List[LinearGroup]
+    model_name: str = "synthetic-linears"
+
+    def parameters_quantized(self) -> int:
+        return sum(w.numel() for g in self.groups for w in g.weights.values())
+
+
+class QuantizedLinears:
+    """Result of ``oneshot`` on a ``LinearCalibrationSet``: the compressed state_dict."""
+
+    def __init__(self, results: Dict[str, Any], recipe, scheme_name: str, fmt: str, weight_config: dict,
+                 ignore: List[str]):
+        self.results = results
+        self.recipe = recipe
+        self.scheme_name = scheme_name
+        self.format = fmt
+        self.weight_config = weight_config
+        self.ignore = ignore
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        from .serialization import result_tensors
+
+        sd: Dict[str, torch.Tensor] = {}
+        for name, r in self.results.items():
+            for k, v in result_tensors(r).items():
+                sd[f"{name}.{k}"] = v
+        return sd
+
+    def quantization_config(self) -> dict:
+        from .serialization import quantization_config
+
+        return quantization_config(self.weight_config, self.format, self.ignore)
+
+    def save_pretrained(self, save_directory, save_compressed: bool = True, **_):
+        from .serialization import save_state
+
+        save_state(self.state_dict(), self.quantization_config(), save_directory)
+
+
+def _iter_batches(acts) -> Iterable[torch.Tensor]:
+    if isinstance(acts, torch.Tensor):
+        yield acts
+    else:
+        for a in acts:
+            yield a
+
+
+def _select_modifiers(recipe) -> Tuple[Optional[SmoothQuantModifier], Optional[GPTQModifier], Optional[AWQModifier]]:
+    mods = recipe if isinstance(recipe, (list, tuple)) else [recipe]
+    sq = next((m for m in mods if isinstance(m, SmoothQuantModifier)), None)
+    gp = next((m for m in mods if isinstance(m, GPTQModifier)), None)
+    aw = next((m for m in mods if isinstance(m, AWQModifier)), None)
+    if gp is None and aw is None:
+        raise ValueError("recipe must contain a GPTQModifier or an AWQModifier")
+    return sq, gp, aw
+
+
+def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLinears:
+    sq, gp, aw = _select_modifiers(recipe)
+    results: Dict[str, Any] = {}
+    if gp is not None:
+        qargs = gp.weight_args()
+        for g in cal.groups:
+            names = [n for n in g.weights if n.split(".")[-1] not in gp.ignore and n not in gp.ignore]
+            if not names:
+                continue
+            K = g.weights[names[0]].shape[1]
+            acc = HessianAccumulator(K, device)
+            for xb in _iter_batches(g.activations):
+                acc.add(xb.to(device), num_samples=None)
+            if g.num_samples is not None:
+                acc.n = int(g.num_samples)
+            res = gptq_quantize_shared([g.weights[n].to(device) for n in names], acc, qargs,
+                                       block_size=gp.block_size, dampening_frac=gp.dampening_frac)
+            results.update(dict(zip(names, res)))
+        mod = gp
+    else:
+        from .awq_linear import awq_quantize_group
+
+        qargs = aw.weight_args()
+        for g in cal.groups:
+            names = [n for n in g.weights if n.split(".")[-1] not in aw.ignore and n not in aw.ignore]
+            if not names:
+                continue
+            res = awq_quantize_group([g.weights[n].to(device) for n in names], _iter_batches(g.activations), qargs,
+                                     n_grid=aw.n_grid, duo_scaling=aw.duo_scaling, device=device)
+            results.update(dict(zip(names, res)))
+        mod = aw
+    return QuantizedLinears(results, recipe, mod.scheme, mod.resolved_scheme.format, qargs.to_config(), list(mod.ignore))
+
+
+def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = None,
+            num_calibration_samples: int = 512, max_seq_length: int = 384,
+            shuffle_calibration_samples: bool = True, save_compressed: bool = True,
+            trust_remote_code_model: bool = False, dataset_path: Optional[str] = None,
+            calibration_dataloader=None, tokenizer=None, processor=None, splits=None,
+            dataset_config_name: Optional[str] = None, text_column: str = "text", pad_to_max_length: bool = False,
+            device: Optional[str] = None, seed: int = 42, **unused):
+    """Counterpart of ``llmcompressor.oneshot`` for the GPTQ / AWQ / SmoothQuant recipes.
+
+    Keyword names are upstream's, because quantool routes ``quantize(**kwargs)`` entries here by
+    matching them against this signature (``base.py:45-72,117-124``).
+    """
+    if recipe is None:
+        raise ValueError("oneshot requires a recipe")
+    from ..hip import _lib
+
+    _lib.load()  # no CPU fallback: fail before touching the model if the HIP library is missing
+    if not torch.cuda.is_available():
+        raise RuntimeError("quantool_amd.oneshot needs an AMD GPU (torch.cuda is not available); "
+                           "there is no CPU path")
+    dev = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+
+    if isinstance(model, LinearCalibrationSet):
+        out = _oneshot_linears(model, recipe, dev)
+    else:
+        from .sequential import oneshot_module
+
+        out = oneshot_module(model, dataset, recipe, dev, num_calibration_samples=num_calibration_samples,
+                             max_seq_length=max_seq_length, shuffle=shuffle_calibration_samples, tokenizer=tokenizer,
+                             dataloader=calibration_dataloader, dataset_path=dataset_path, text_column=text_column,
+                             trust_remote_code=trust_remote_code_model, seed=seed)
+    if output_dir:
+        Path(output_dir).mkdir(parents=True, exist_ok=True)
+        out.save_pretrained(str(output_dir), save_compressed=save_compressed)
+    return out

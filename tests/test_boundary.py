@@ -1,0 +1,267 @@
+"""The drop-in boundary: registry, plugin classes and the kwargs routing of ``quantize`` behave as
+the reference's ``quantool.core`` / ``quantool.methods.llm_compressor`` do.  The engine
+is replaced by a recording fake here, as the reference's own method tests do with mocks."""
+import logging
+from pathlib import Path
+
+import pytest
+import yaml
+
+import quantool_amd.methods  # noqa: F401  (registers the plugins)
+from quantool_amd.core import BaseQuantizer, QuantizerRegistry, Registry, TemplateQuantizationCard
+from quantool_amd.engine.modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
+from quantool_amd.methods.hip_compressor.base import HipCompressorQuantizer
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+# ----------------------------------------------------------------------------------- registry
+def test_registry_lists_the_three_calibration_methods():
+    assert {"gptq", "awq", "smoothquant"} <= set(QuantizerRegistry.list())
+
+
+def test_registry_semantics_match_reference():
+    reg = Registry()
+
+    class NoName:
+        pass
+
+    with pytest.raises(ValueError, match="must have a 'name' attribute"):
+        reg.register(NoName)
+
+    class A(BaseQuantizer):
+        name = "a"
+        supported_levels = []
+
+        def quantize(self, model, level, **kw):
+            return "x"
+
+    assert reg.register(A) is A
+    with pytest.raises(KeyError, match="already registered"):
+        reg.register(A)
+    inst = reg.create("a", model_id="m/n")
+    assert isinstance(inst, A) and inst.model_id == "m/n"
+    assert reg.list() == ["a"]
+    with pytest.raises(KeyError):
+        reg.create("missing")
+
+
+def test_duplicate_name_cannot_coregister():
+    with pytest.raises(KeyError):
+        @QuantizerRegistry.register
+        class Again(HipCompressorQuantizer):  # noqa: F811
+            name = "gptq"
+
+
+@pytest.mark.parametrize("name,levels", [
+    ("gptq", ["W4A16", "W8A8", "INT8", "W8A16", "W4A16_ASYM", "W4A8"]),
+    ("awq", ["W4A16", "W4A16_ASYM", "W8A16"]),
+    ("smoothquant", ["W8A8", "INT8", "W4A8"]),
+])
+def test_class_attributes(name, levels):
+    q = QuantizerRegistry.create(name, model_id="org/model", targets="Linear", ignore=["lm_head"])
+    assert q.name == name and q.supported_levels == levels
+    assert q.supports_multiple_levels is False
+    assert isinstance(q.template_card, TemplateQuantizationCard)
+    assert q.template_card.hyperparameters["num_calibration_samples"] == 512
+    assert q.require_calibration() is True
+    assert q.last_model is None and q.last_output_dir is None and q._last_recipe is None
+
+
+# ----------------------------------------------------------------------------------- recipes
+def test_gptq_recipe_defaults_and_passthrough():
+    q = QuantizerRegistry.create("gptq", model_id="m")
+    recipe, scheme = q._build_recipe(None, {})
+    assert isinstance(recipe, GPTQModifier) and scheme == "W4A16"
+    assert recipe.targets == ["Linear"] and recipe.ignore == ["lm_head"]
+    assert recipe.block_size == 128 and recipe.dampening_frac == 0.01
+    recipe, scheme = q._build_recipe("W4A16_ASYM", {"scheme": "W8A16", "block_size": 64, "dampening_frac": 0.1,
+                                                    "sequential_targets": ["LlamaDecoderLayer"], "actorder": "group"})
+    assert scheme == "W4A16_ASYM"                       # level wins over method_kwargs["scheme"]
+    assert recipe.block_size == 64 and recipe.dampening_frac == 0.1
+    assert recipe.sequential_targets == ["LlamaDecoderLayer"]
+    assert recipe.actorder == "static"                  # only the three documented keys pass through
+    assert not recipe.weight_args().symmetric
+
+
+def test_invalid_scheme_is_a_value_error_with_the_reference_wording():
+    for name in ("gptq", "awq", "smoothquant"):
+        q = QuantizerRegistry.create(name, model_id="m")
+        with pytest.raises(ValueError, match="is not a valid compressed-tensors preset scheme"):
+            q._build_recipe("W3A16", {})
+
+
+def test_unsupported_level_only_warns(caplog):
+    q = QuantizerRegistry.create("awq", model_id="m")
+    with caplog.at_level(logging.WARNING):
+        recipe, scheme = q._build_recipe("W8A8", {})
+    assert scheme == "W8A8" and isinstance(recipe, AWQModifier)
+    assert any("AWQ only supports weight-only" in r.message for r in caplog.records)
+
+
+def test_awq_and_smoothquant_recipes():
+    a = QuantizerRegistry.create("awq", model_id="m")
+    recipe, scheme = a._build_recipe(None, {"mappings": [["x"]], "smoothing_strength": 0.7, "block_size": 1})
+    assert scheme == "W4A16" and recipe.mappings == [["x"]] and recipe.smoothing_strength == 0.7
+    s = QuantizerRegistry.create("smoothquant", model_id="m")
+    recipe, scheme = s._build_recipe(None, {"block_size": 64})
+    assert scheme == "W8A8" and len(recipe) == 2
+    assert isinstance(recipe[0], SmoothQuantModifier) and recipe[0].smoothing_strength == 0.5
+    assert isinstance(recipe[1], GPTQModifier) and recipe[1].block_size == 128   # no pass-through to stage 2
+    assert recipe[1].weight_args().num_bits == 8 and recipe[1].weight_args().strategy == "channel"
+
+
+# ----------------------------------------------------------------------------------- quantize()
+class _FakeModel:
+    def __init__(self):
+        self.saved = None
+
+    def save_pretrained(self, dest, save_compressed=False):
+        self.saved = (dest, save_compressed)
+
+
+@pytest.fixture
+def fake_engine(monkeypatch):
+    calls = {}
+
+    def fake_oneshot(model=None, dataset=None, recipe=None, output_dir=None, num_calibration_samples=512,
+                     max_seq_length=384, save_compressed=True, trust_remote_code_model=False, dataset_path=None,
+                     calibration_dataloader=None):
+        calls.update(model=model, dataset=dataset, recipe=recipe, output_dir=output_dir,
+                     num_calibration_samples=num_calibration_samples, max_seq_length=max_seq_length,
+                     save_compressed=save_compressed, trust_remote_code_model=trust_remote_code_model,
+                     dataset_path=dataset_path)
+        return _FakeModel()
+
+    monkeypatch.setattr(HipCompressorQuantizer, "_import_oneshot_static", staticmethod(lambda: fake_oneshot))
+    monkeypatch.setattr(HipCompressorQuantizer, "_ONESHOT_PARAMS_CACHE", None)
+    yield calls
+    HipCompressorQuantizer._ONESHOT_PARAMS_CACHE = None
+
+
+def test_kwargs_routing_truth_table(fake_engine, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    q = QuantizerRegistry.create("gptq", model_id="org/model")
+    out = q.quantize(
+        model="/local/model", level="W4A16", dataset=["row"],
+        # 1. names in oneshot's signature flow into oneshot kwargs ...
+        num_calibration_samples=32, max_seq_length=256,
+        # ... but an explicit oneshot_kwargs entry wins (setdefault)
+        oneshot_kwargs={"max_seq_length": 128},
+        # 2. method_kwargs__X populates method_kwargs[X]
+        method_kwargs__block_size=64,
+        # 3. anything else is silently dropped -- e.g. the YAML's top-level targets / ignore
+        targets="Embedding", ignore=["nothing"], bogus=1,
+    )
+    assert fake_engine["num_calibration_samples"] == 32
+    assert fake_engine["max_seq_length"] == 128
+    assert fake_engine["recipe"].block_size == 64
+    assert fake_engine["recipe"].targets == ["Linear"] and fake_engine["recipe"].ignore == ["lm_head"]
+    assert fake_engine["model"] == "/local/model" and fake_engine["dataset"] == ["row"]
+    assert fake_engine["save_compressed"] is True and fake_engine["trust_remote_code_model"] is True
+    # default output dir: ./output/{name}_{model_id with / -> _}_{level}, created eagerly, returned resolved
+    expect = (tmp_path / "output" / "gptq_org_model_W4A16").resolve()
+    assert out == str(expect) and expect.is_dir()
+    assert q.last_output_dir == expect and q.source_model == "/local/model"
+    assert isinstance(q.last_model, _FakeModel) and q._last_recipe is fake_engine["recipe"]
+
+
+def test_missing_calibration_source_raises_value_error(fake_engine, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    q = QuantizerRegistry.create("gptq", model_id="m")
+    with pytest.raises(ValueError, match="require calibration data"):
+        q.quantize(model="/local/model", level="W4A16")
+    # dataset_path is also a calibration source
+    q.quantize(model="/local/model", level="W4A16", dataset_path="/data/calib.json")
+    assert fake_engine["dataset_path"] == "/data/calib.json"
+
+
+def test_explicit_recipe_and_list_level(fake_engine, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    q = QuantizerRegistry.create("gptq", model_id="m")
+    marker = object()
+    q.quantize(model="x", recipe=marker, dataset=[1], oneshot_kwargs={"output_dir": str(tmp_path / "o")})
+    assert fake_engine["recipe"] is marker and fake_engine["output_dir"] == str(tmp_path / "o")
+    with pytest.raises(ValueError, match="does not support multiple quantization levels"):
+        q.quantize(model="x", level=["W4A16", "W8A16"], dataset=[1])
+
+
+def test_engine_failure_is_logged_and_reraised(monkeypatch, tmp_path, caplog):
+    monkeypatch.chdir(tmp_path)
+
+    def boom(**kw):
+        raise RuntimeError("engine exploded")
+
+    monkeypatch.setattr(HipCompressorQuantizer, "_import_oneshot_static", staticmethod(lambda: boom))
+    monkeypatch.setattr(HipCompressorQuantizer, "_ONESHOT_PARAMS_CACHE", None)
+    q = QuantizerRegistry.create("gptq", model_id="m")
+    with caplog.at_level(logging.ERROR), pytest.raises(RuntimeError, match="engine exploded"):
+        q.quantize(model="x", level="W4A16", dataset=[1])
+    assert any("oneshot failed" in r.message for r in caplog.records)
+    HipCompressorQuantizer._ONESHOT_PARAMS_CACHE = None
+
+
+def test_save_pretrained_contract(fake_engine, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    q = QuantizerRegistry.create("gptq", model_id="m")
+    with pytest.raises(RuntimeError, match="No quantized model available"):
+        q.save_pretrained(str(tmp_path / "out"))
+    q.quantize(model="x", level="W4A16", dataset=[1])
+
+    class Tok:
+        def save_pretrained(self, d):
+            Path(d, "tokenizer.json").write_text("{}")
+
+    q.last_tokenizer = Tok()
+    q.save_pretrained(str(tmp_path / "out"))
+    assert q.last_model.saved == (str(tmp_path / "out"), True)      # save_compressed=True (base.py:188)
+    assert (tmp_path / "out" / "tokenizer.json").exists()
+    q.save_model_card(str(tmp_path / "out"))
+    assert "GPTQ Quantization" in (tmp_path / "out" / "README.md").read_text()
+
+
+def test_yaml_field_set_drives_the_plugin(fake_engine, tmp_path, monkeypatch):
+    """config #1 plumbing: YAML (reference field set) -> registry -> plugin -> engine, as
+    cli.quantize_step does (cli.py:201-203, 341-350)."""
+    monkeypatch.chdir(tmp_path)
+    cfg = yaml.safe_load((GOLD / "plumbing_gptq_config.yaml").read_text())
+    assert cfg["method"] in QuantizerRegistry.list()
+    qcfg = cfg["quantization_config"]
+    quantizer = QuantizerRegistry.create(cfg["method"], model_id=cfg["model_id"], **qcfg)
+    assert quantizer.require_calibration()
+    dataset = [{"text": "hello"}] * cfg["sample_size"]
+    dataset = quantizer.prepare_calibration_data(dataset, tokenizer=None)
+    out = quantizer.quantize(model="/models/local", level=cfg["quant_level"], dataset=dataset, **qcfg)
+    assert out.endswith("gptq_synthetic_opt-125m-shaped_W4A16")
+    assert fake_engine["recipe"].scheme == "W4A16" and len(fake_engine["dataset"]) == 32
+
+
+def test_prepare_calibration_data_text_fallback():
+    q = QuantizerRegistry.create("gptq", model_id="m")
+
+    class DS:
+        def __init__(self, rows, cols):
+            self.rows, self.column_names = rows, cols
+
+        def map(self, fn, batched=False):
+            rows = [{**r, **fn(r)} for r in self.rows]
+            return DS(rows, sorted({k for r in rows for k in r}))
+
+    ds = q.prepare_calibration_data(DS([{"prompt": "p"}], ["prompt"]))
+    assert "text" in ds.column_names and ds.rows[0]["text"] == "p"
+    ds2 = DS([{"text": "t"}], ["text"])
+    assert q.prepare_calibration_data(ds2) is ds2
+    ds3 = DS([{"other": 1}], ["other"])
+    assert q.prepare_calibration_data(ds3) is ds3      # nothing usable: unchanged, engine will complain
+
+
+def test_oneshot_refuses_to_run_without_gpu_or_library():
+    """No CPU fallback: on a box without a GPU the engine raises instead of computing."""
+    import torch
+
+    from quantool_amd.engine.oneshot import LinearCalibrationSet, oneshot
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises((RuntimeError, ImportError)):
+        oneshot(model=LinearCalibrationSet(groups=[]), recipe=GPTQModifier(), dataset=[1])
