@@ -66,12 +66,14 @@ def quantize_layer(shape, weights, acts, qargs, n_samples):
     """One step: the hot path over one decoder layer.  Returns the packed outputs."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
 
-    outs = []
+    outs = {}
     for (gname, K, lins) in shape.groups:
         acc = HessianAccumulator(K, acts[gname].device)
         acc.add(acts[gname], num_samples=n_samples)
         res = gptq_quantize_shared([weights[n] for n, _ in lins], acc, qargs)
-        outs.extend((r.weight_packed, r.weight_scale) for r in res)
+        for (lname, _), r in zip(lins, res):
+            outs[f"{lname}.weight_packed"] = r.weight_packed
+            outs[f"{lname}.weight_scale"] = r.weight_scale
         del acc, res
     return outs
 
@@ -193,11 +195,12 @@ def main():
         kept.append(quantize_layer(shape, weights, acts, qargs, args.samples))
     if dist is not None:
         # final gather of the packed state to rank 0 (the job's only collective)
-        for outs in kept:
-            for packed, scale in outs:
-                for t in (packed, scale.view(torch.int16)):
-                    gl = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-                    dist.gather(t, gl, dst=0)
+        from quantool_amd.engine.sharding import gather_state_dict
+
+        local = {f"layers.{rank + world * i}.{k}": v for i, outs in enumerate(kept) for k, v in outs.items()}
+        merged = gather_state_dict(local, dst=0, device=dev)
+        if rank == 0:
+            assert len(merged) == len(local) * world
     barrier()
     elapsed = time.perf_counter() - t0
 
