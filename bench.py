@@ -62,20 +62,45 @@ def synth_weight(R: int, K: int, seed: int, device) -> torch.Tensor:
     return (torch.randn((R, K), generator=g, device=device) * 0.02).to(torch.bfloat16)
 
 
-def quantize_layer(shape, weights, acts, qargs, n_samples):
-    """One step: the hot path over one decoder layer.  Returns the packed outputs."""
+_STREAMS = {}
+
+
+def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0):
+    """One step: the hot path over one decoder layer.  Returns the packed outputs.
+
+    The layer's Linear groups are independent, so each runs on its own HIP stream: the
+    latency-bound factorisation / sweep chains of one group overlap the MFMA-bound Gram pass of
+    another.  The largest-K group is issued first (longest chain).  `lane` selects one of two
+    stream sets so that two consecutive layers (independent units in this per-Linear mode, exactly
+    as across GPUs) can be in flight at once."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
 
+    dev = next(iter(acts.values())).device
     outs = {}
-    for (gname, K, lins) in shape.groups:
-        acc = HessianAccumulator(K, acts[gname].device)
-        acc.add(acts[gname], num_samples=n_samples)
-        res = gptq_quantize_shared([weights[n] for n, _ in lins], acc, qargs)
-        for (lname, _), r in zip(lins, res):
-            outs[f"{lname}.weight_packed"] = r.weight_packed
-            outs[f"{lname}.weight_scale"] = r.weight_scale
-        del acc, res
+    groups = sorted(shape.groups, key=lambda g: -g[1]) if overlap else list(shape.groups)
+    main = torch.cuda.current_stream(dev)
+    for gi, (gname, K, lins) in enumerate(groups):
+        if overlap:
+            st = _STREAMS.setdefault((dev.index, lane, gi), torch.cuda.Stream(device=dev))
+            st.wait_stream(main)
+        else:
+            st = main
+        with torch.cuda.stream(st):
+            acc = HessianAccumulator(K, dev)
+            acc.add(acts[gname], num_samples=n_samples)
+            res = gptq_quantize_shared([weights[n] for n, _ in lins], acc, qargs)
+            for (lname, _), r in zip(lins, res):
+                outs[f"{lname}.weight_packed"] = r.weight_packed
+                outs[f"{lname}.weight_scale"] = r.weight_scale
+            del acc, res
     return outs
+
+
+def join_streams(dev):
+    main = torch.cuda.current_stream(dev)
+    for key, st in _STREAMS.items():
+        if key[0] == dev.index:
+            main.wait_stream(st)
 
 
 def host_cores() -> int:
@@ -143,6 +168,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -184,7 +210,8 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        quantize_layer(shape, weights, acts, qargs, args.samples)
+        quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap)
+    join_streams(dev)
     barrier()
 
     lib.qt_profile_enable(1)
@@ -192,7 +219,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        kept.append(quantize_layer(shape, weights, acts, qargs, args.samples))
+        kept.append(quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap,
+                                   lane=_ % 2))
+    join_streams(dev)
     if dist is not None:
         # final gather of the packed state to rank 0 (the job's only collective)
         from quantool_amd.engine.sharding import gather_state_dict

@@ -43,7 +43,8 @@ def _req(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None):
 
 def workspace(nbytes: int, device, tag: str = "default") -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag); reused across calls on the same stream."""
-    key = (str(device), tag)
+    # one scratch buffer per (device, stream, tag): groups running on different streams never share
+    key = (str(device), _stream(), tag)
     buf = _WS_CACHE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
