@@ -124,6 +124,42 @@ int qt_dequantize(const int8_t* Qt, int R, int K, const int32_t* col_src, const 
                   const float* zp, int G, const int32_t* g_of_col, void* out, int out_dtype,
                   int64_t ldo, qt_stream_t stream);
 
+/* ---- a12  AWQ scale search (AWQModifier under awq.py:81) ----------------------------------------
+ * w_sum[K] += sum_rows |w| / (group absmax + 1e-6) (call once per balance layer; w_mean = w_sum /
+ * total rows).  group_size: multiple of 64, <= 512, dividing K. */
+size_t qt_awq_weight_mean_workspace_bytes(int R, int K);
+int qt_awq_weight_mean_accumulate(const void* W, int w_dtype, int R, int K, int64_t ldw, int group_size,
+                                  float* w_sum, void* workspace, size_t workspace_bytes,
+                                  qt_stream_t stream);
+/* scales[g][k], g = 0..n_grid-1 (ratio g/n_grid): s = clamp(x_mean^r / (w_mean^(1-r) + 1e-4), 1e-4),
+ * s /= sqrt(max s * min s), inf/nan -> 1.  x_mean = x_abs_sum / n_tokens (qt_act_stats_accumulate). */
+int qt_awq_scales(const float* x_abs_sum, int64_t n_tokens, const float* w_sum, int64_t n_rows, int K,
+                  int n_grid, int duo_scaling, float* scales, qt_stream_t stream);
+/* Mirror the lower triangle of the Gram sum into the upper one (G full symmetric afterwards). */
+int qt_symmetrize_lower(float* G, int K, qt_stream_t stream);
+/* loss_out[0] (device fp32) = mean((X W^T - X Wq^T)^2) with Wq = pseudo_quant(W*s)/s, evaluated as
+ * sum_r d_r G d_r^T / (n_tokens * R), D = W - Wq, G = X^T X full symmetric (see awq.hip header). */
+size_t qt_awq_loss_workspace_bytes(int R, int K);
+int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
+                int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, float* loss_out,
+                void* workspace, size_t workspace_bytes, qt_stream_t stream);
+/* out = W * s[None, :] (divide != 0: W / s), rounded to W's dtype (AWQ / SmoothQuant apply step). */
+int qt_scale_columns(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int divide,
+                     void* out, int64_t ldo, qt_stream_t stream);
+/* Plain round-to-nearest levels Qt[K,R] under the given group parameters (AWQ's final step; also
+ * the U = I degenerate case of the sweep). */
+int qt_rtn_quantize(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* scale,
+                    const float* zp, int G, int group_size, int num_bits, int8_t* Qt, qt_stream_t stream);
+
+/* ---- a13  SmoothQuant (SmoothQuantModifier under smoothquant.py:77) -----------------------------
+ * wmax[k] = max(wmax[k], max_r |W[r,k]|);  s = (cmax-cmin)^alpha / wmax^(1-alpha), s = cmax-cmin
+ * where wmax == 0. */
+size_t qt_col_absmax_workspace_bytes(int R, int K);
+int qt_col_absmax_accumulate(const void* W, int w_dtype, int R, int K, int64_t ldw, float* wmax,
+                             void* workspace, size_t workspace_bytes, qt_stream_t stream);
+int qt_smoothquant_scales(const float* cmin, const float* cmax, const float* wmax, int K, float alpha,
+                          float* s, qt_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference surface) -------------
  * When enabled, HIP events are recorded on the launch stream immediately around the named
  * kernel; qt_profile_read synchronises them, returns the summed device time and the launch

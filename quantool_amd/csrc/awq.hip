@@ -1,0 +1,402 @@
+// a12 / a13: AWQ per-channel scale search and SmoothQuant scales (SURVEY.md 8a rows a12, a13;
+// upstream AWQModifier._compute_best_scale / _pseudo_quantize_tensor / _compute_layer_means and
+// SmoothQuantModifier._calculate_smoothing_scales, reached through awq.py:81 / smoothquant.py:77).
+//
+// The search loss  mean((X W^T - X Wq^T)^2)  is evaluated through the Gram matrix the GPTQ path
+// already builds:  sum_r d_r (X^T X) d_r^T / (N R)  with  D = W - pseudo_quant(W s)/s.  That is the
+// same number (exact algebra) for 2 R K^2 flops per grid point instead of 2 N R K -- N/K = 48x
+// fewer at K = 4096 -- and it turns the 20-point search into fp32 MFMA work on resident data.
+#include "common.h"
+#include "sgemm_tn.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float load_w(const void* W, int dtype, size_t idx) {
+    if (dtype == QT_F32) return ((const float*)W)[idx];
+    return qt_bf16_to_f32(((const unsigned short*)W)[idx]);
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+constexpr int WM_ROWS = 64;  // rows per workgroup in the weight-mean pass
+
+// partial[chunk][k] = sum over the chunk's rows of |w[r][k]| / (group amax + 1e-6); one wave per
+// (group, row chunk), each lane owns gs/64 columns of the group (gs <= 512).
+__global__ __launch_bounds__(64) void awq_wmean_partial_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                               int64_t ldw, int gs, float* __restrict__ partial) {
+    const int g = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x;
+    const int per = gs / 64;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    const int r0 = chunk * WM_ROWS, r1 = (r0 + WM_ROWS < R) ? r0 + WM_ROWS : R;
+    for (int r = r0; r < r1; ++r) {
+        float v[8];
+        float m = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = 0.0f;
+            if (e < per) {
+                v[e] = fabsf(load_w(W, dtype, (size_t)r * ldw + (size_t)g * gs + e * 64 + lane));
+                m = fmaxf(m, v[e]);
+            }
+        }
+        m = wave_max(m) + 1e-6f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < per) acc[e] = acc[e] + v[e] / m;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e < per) partial[(size_t)chunk * K + (size_t)g * gs + e * 64 + lane] = acc[e];
+}
+
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ partial, int n_chunks, int K,
+                                                        float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.0f;
+    for (int c = 0; c < n_chunks; ++c) s = s + partial[(size_t)c * K + k];
+    out[k] = out[k] + s;
+}
+
+// scales[g][k] for the n_grid ratios g/n_grid (one workgroup):
+//   s = clamp(x_mean^r / (w_mean^(1-r) + 1e-4), 1e-4);  s /= sqrt(max s * min s);  nan/inf -> 1
+__global__ __launch_bounds__(1024) void awq_scales_kernel(const float* __restrict__ x_sum, float inv_tokens,
+                                                          const float* __restrict__ w_sum, float inv_rows, int K,
+                                                          int n_grid, int duo, float* __restrict__ scales) {
+    __shared__ float smax[16], smin[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int gi = 0; gi < n_grid; ++gi) {
+        const float r = (float)gi / (float)n_grid;
+        float mx = -INFINITY, mn = INFINITY;
+        for (int k = tid; k < K; k += 1024) {
+            const float xm = x_sum[k] * inv_tokens, wm = w_sum[k] * inv_rows;
+            float s = duo ? powf(xm, r) / (powf(wm, 1.0f - r) + 1e-4f) : powf(xm, r);
+            s = fmaxf(s, 1e-4f);
+            scales[(size_t)gi * K + k] = s;
+            mx = fmaxf(mx, s);
+            mn = fminf(mn, s);
+        }
+        mx = wave_max(mx);
+        mn = wave_min(mn);
+        if (lane == 0) {
+            smax[wave] = mx;
+            smin[wave] = mn;
+        }
+        __syncthreads();
+        mx = smax[0];
+        mn = smin[0];
+        for (int w = 1; w < 16; ++w) {
+            mx = fmaxf(mx, smax[w]);
+            mn = fminf(mn, smin[w]);
+        }
+        const float nrm = sqrtf(mx * mn);
+        for (int k = tid; k < K; k += 1024) {
+            float s = scales[(size_t)gi * K + k] / nrm;
+            if (!(fabsf(s) <= 3.4028234e38f)) s = 1.0f;  // inf or nan
+            scales[(size_t)gi * K + k] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// Dt[k][r] = w - pseudo_quant(w * s_k) / s_k, one wave per (row, group), transposed through the
+// write index (lanes = columns; Dt rows are R long so a wave writes 64 scattered floats -- the
+// matrix is written once and read by the GEMM 20x less often than it is computed).
+__global__ __launch_bounds__(64) void awq_diff_t_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                        int64_t ldw, const float* __restrict__ s, int gs,
+                                                        int symmetric, int num_bits, float* __restrict__ Dt) {
+    const int g = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const int per = gs / 64;
+    float w[8], ws[8];
+    float mx = -INFINITY, mn = INFINITY, amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        w[e] = ws[e] = 0.0f;
+        if (e < per) {
+            const int k = g * gs + e * 64 + lane;
+            w[e] = load_w(W, dtype, (size_t)r * ldw + k);
+            ws[e] = w[e] * s[k];
+            mx = fmaxf(mx, ws[e]);
+            mn = fminf(mn, ws[e]);
+            amax = fmaxf(amax, fabsf(ws[e]));
+        }
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    amax = wave_max(amax);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (e < per) {
+            const int k = g * gs + e * 64 + lane;
+            float q;
+            if (symmetric) {
+                const float max_int = (float)((1 << (num_bits - 1)) - 1), min_int = -(float)(1 << (num_bits - 1));
+                const float sc = fmaxf(amax, 1e-5f) / max_int;
+                q = fminf(fmaxf(rintf(ws[e] / sc), min_int), max_int) * sc;
+            } else {
+                const float max_int = (float)((1 << num_bits) - 1);
+                const float sc = fmaxf(mx - mn, 1e-5f) / max_int;
+                const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
+                q = (fminf(fmaxf(rintf(ws[e] / sc) + z, 0.0f), max_int) - z) * sc;
+            }
+            Dt[(size_t)k * R + r] = w[e] - q / s[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ G, int K) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < K && j > i) G[(size_t)i * K + j] = G[(size_t)j * K + i];
+}
+
+__global__ __launch_bounds__(256) void partial_sum_f64_kernel(const float* __restrict__ partial, int n, double scale,
+                                                              float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
+}
+
+// out[r][k] = W[r][k] * s[k]  (fp32 product rounded to the output dtype, as `weight * scales`)
+__global__ __launch_bounds__(256) void scale_columns_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                            int64_t ldw, const float* __restrict__ s, int divide,
+                                                            void* __restrict__ out, int64_t ldo) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (k >= K) return;
+    const float w = load_w(W, dtype, (size_t)r * ldw + k);
+    const float v = divide ? w / s[k] : w * s[k];
+    if (dtype == QT_F32) ((float*)out)[(size_t)r * ldo + k] = v;
+    else ((__bf16*)out)[(size_t)r * ldo + k] = (__bf16)v;
+}
+
+// cmax[k] = max(cmax[k], max_r |W[r][k]|): thread per column, rows strided over blockIdx.y chunks
+__global__ __launch_bounds__(256) void col_absmax_partial_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                                 int64_t ldw, int rows_per, float* __restrict__ part) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int r0 = blockIdx.y * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
+    float m = 0.0f;
+    for (int r = r0; r < r1; ++r) m = fmaxf(m, fabsf(load_w(W, dtype, (size_t)r * ldw + k)));
+    part[(size_t)blockIdx.y * K + k] = m;
+}
+__global__ __launch_bounds__(256) void chunk_max_kernel(const float* __restrict__ part, int n_chunks, int K,
+                                                        float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float m = out[k];
+    for (int c = 0; c < n_chunks; ++c) m = fmaxf(m, part[(size_t)c * K + k]);
+    out[k] = m;
+}
+
+// s = a^alpha / w^(1-alpha), a = cmax - cmin;  where w == 0: s = a
+__global__ __launch_bounds__(256) void smooth_scales_kernel(const float* __restrict__ cmin,
+                                                            const float* __restrict__ cmax,
+                                                            const float* __restrict__ wmax, int K, float alpha,
+                                                            float* __restrict__ s) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float a = cmax[k] - cmin[k], w = wmax[k];
+    s[k] = (w > 0.0f) ? powf(a, alpha) / powf(w, 1.0f - alpha) : a;
+}
+
+// Qt[k][r] = level of W[r][k] under plain round-to-nearest with the given group parameters
+__global__ __launch_bounds__(256) void rtn_kernel(const void* __restrict__ W, int dtype, int R, int K, int64_t ldw,
+                                                  const float* __restrict__ scale, const float* __restrict__ zp,
+                                                  int G, int gs, float qmin, float qmax, int8_t* __restrict__ Qt) {
+    __shared__ int8_t tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int cl = e & 63, rl = e >> 6;
+        const int r = r0 + rl, c = c0 + cl;
+        int8_t q = 0;
+        if (r < R && c < K) {
+            const int g = c / gs;
+            const float sc = scale[(size_t)r * G + g], z = zp[(size_t)r * G + g];
+            float x = load_w(W, dtype, (size_t)r * ldw + c) / sc;
+            x = x + z;
+            x = fminf(fmaxf(x, qmin), qmax);
+            q = (int8_t)rintf(x);
+        }
+        tile[rl][cl] = q;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int rl = e & 63, cl = e >> 6;
+        const int r = r0 + rl, c = c0 + cl;
+        if (r < R && c < K) Qt[(size_t)c * R + r] = tile[rl][cl];
+    }
+}
+
+}  // namespace
+
+extern "C" size_t qt_awq_weight_mean_workspace_bytes(int R, int K) {
+    if (R <= 0 || K <= 0) return 0;
+    return (size_t)((R + WM_ROWS - 1) / WM_ROWS) * K * 4 + 256;
+}
+
+extern "C" int qt_awq_weight_mean_accumulate(const void* W, int w_dtype, int R, int K, int64_t ldw, int group_size,
+                                             float* w_sum, void* workspace, size_t workspace_bytes,
+                                             qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && w_sum && R > 0 && K > 0, "qt_awq_weight_mean_accumulate: bad arguments");
+    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_awq_weight_mean_accumulate: dtype");
+    const int gs = group_size <= 0 ? K : group_size;
+    if (K % gs != 0 || gs % 64 != 0 || gs > 512) {
+        qt_set_error("qt_awq_weight_mean_accumulate: group_size %d unsupported (multiple of 64, <= 512, dividing K)", gs);
+        return QT_ERR_UNSUPPORTED;
+    }
+    const size_t need = qt_awq_weight_mean_workspace_bytes(R, K);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_awq_weight_mean_accumulate: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    float* partial = (float*)qt_align_up((size_t)workspace, 256);
+    const int chunks = (R + WM_ROWS - 1) / WM_ROWS;
+    hipLaunchKernelGGL(awq_wmean_partial_kernel, dim3(K / gs, chunks), dim3(64), 0, stream, W, w_dtype, R, K, ldw, gs,
+                       partial);
+    QT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, (const float*)partial, chunks, K,
+                       w_sum);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_awq_scales(const float* x_abs_sum, int64_t n_tokens, const float* w_sum, int64_t n_rows, int K,
+                             int n_grid, int duo_scaling, float* scales, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(x_abs_sum && w_sum && scales && K > 0 && n_grid > 0 && n_tokens > 0 && n_rows > 0,
+                 "qt_awq_scales: bad arguments");
+    hipLaunchKernelGGL(awq_scales_kernel, dim3(1), dim3(1024), 0, stream, x_abs_sum, (float)(1.0 / (double)n_tokens),
+                       w_sum, (float)(1.0 / (double)n_rows), K, n_grid, duo_scaling, scales);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_symmetrize_lower(float* G, int K, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(G && K > 0, "qt_symmetrize_lower: bad arguments");
+    hipLaunchKernelGGL(symmetrize_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, G, K);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" size_t qt_awq_loss_workspace_bytes(int R, int K) {
+    if (R <= 0 || K <= 0) return 0;
+    const size_t tiles = (size_t)((R + 63) / 64) * ((K + 63) / 64);
+    return (size_t)R * K * 4 + tiles * 4 + 1024;
+}
+
+extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
+                           int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, float* loss_out,
+                           void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && s && Gfull && loss_out && R > 0 && K > 0 && n_tokens > 0, "qt_awq_loss: bad arguments");
+    const int gs = group_size <= 0 ? K : group_size;
+    if (K % gs != 0 || gs % 64 != 0 || gs > 512) {
+        qt_set_error("qt_awq_loss: group_size %d unsupported", gs);
+        return QT_ERR_UNSUPPORTED;
+    }
+    const size_t need = qt_awq_loss_workspace_bytes(R, K);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_awq_loss: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    float* Dt = (float*)qt_align_up((size_t)workspace, 256);
+    float* partial = Dt + (size_t)R * K;
+    hipLaunchKernelGGL(awq_diff_t_kernel, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s, gs, symmetric,
+                       num_bits, Dt);
+    QT_LAUNCH_CHECK();
+    int n_partial = 0;
+    SgemmArgs g;
+    g.A = Dt; g.lda = R;
+    g.B = Gfull; g.ldb = K;
+    g.Cin = Dt; g.ldcin = R;       // DOT mode reads E[row][col] = Cin[col * ldcin + row]
+    g.Cout = partial; g.ldcout = 0;
+    g.M = R; g.N = K; g.kdim = K; g.k_mode = SG_K_FULL; g.mode = SG_MODE_DOT;
+    const int rc = qt_sgemm_tn_dot(g, stream, &n_partial);
+    if (rc) return rc;
+    hipLaunchKernelGGL(partial_sum_f64_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, n_partial,
+                       1.0 / ((double)n_tokens * (double)R), loss_out);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_scale_columns(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int divide,
+                                void* out, int64_t ldo, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && s && out && R > 0 && K > 0, "qt_scale_columns: bad arguments");
+    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_scale_columns: dtype");
+    hipLaunchKernelGGL(scale_columns_kernel, dim3((K + 255) / 256, R), dim3(256), 0, stream, W, w_dtype, R, K, ldw, s,
+                       divide, out, ldo);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" size_t qt_col_absmax_workspace_bytes(int R, int K) {
+    if (R <= 0 || K <= 0) return 0;
+    return (size_t)((R + 127) / 128) * K * 4 + 256;
+}
+
+extern "C" int qt_col_absmax_accumulate(const void* W, int w_dtype, int R, int K, int64_t ldw, float* wmax,
+                                        void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && wmax && R > 0 && K > 0, "qt_col_absmax_accumulate: bad arguments");
+    const size_t need = qt_col_absmax_workspace_bytes(R, K);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_col_absmax_accumulate: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    float* part = (float*)qt_align_up((size_t)workspace, 256);
+    const int chunks = (R + 127) / 128;
+    hipLaunchKernelGGL(col_absmax_partial_kernel, dim3((K + 255) / 256, chunks), dim3(256), 0, stream, W, w_dtype, R, K,
+                       ldw, 128, part);
+    QT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_max_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, (const float*)part, chunks, K,
+                       wmax);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_smoothquant_scales(const float* cmin, const float* cmax, const float* wmax, int K, float alpha,
+                                     float* s, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(cmin && cmax && wmax && s && K > 0, "qt_smoothquant_scales: bad arguments");
+    hipLaunchKernelGGL(smooth_scales_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, cmin, cmax, wmax, K, alpha,
+                       s);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_rtn_quantize(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* scale,
+                               const float* zp, int G, int group_size, int num_bits, int8_t* Qt,
+                               qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && scale && zp && Qt && R > 0 && K > 0 && G > 0, "qt_rtn_quantize: bad arguments");
+    const int gs = group_size <= 0 ? K : group_size;
+    QT_CHECK_ARG(K % gs == 0 && K / gs == G, "qt_rtn_quantize: G != K / group_size");
+    const float qmin = -(float)(1 << (num_bits - 1)), qmax = (float)((1 << (num_bits - 1)) - 1);
+    hipLaunchKernelGGL(rtn_kernel, dim3((K + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, W, w_dtype, R, K, ldw,
+                       scale, zp, G, gs, qmin, qmax, Qt);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}

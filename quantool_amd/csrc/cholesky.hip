@@ -344,7 +344,7 @@ extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
     if (K <= 0) return 0;
     const size_t nb = (K + NB - 1) / NB;
     // P panel [128, K] + T panel [128, K] + Rd, Dinv [nb][128*128] each + split-K slabs
-    return 2 * (size_t)NB * K * 4 + nb * (NB * NB + RD_STRIDE) * 4 + (size_t)16 * NB * K * 4 + 256;
+    return 2 * (size_t)NB * K * 4 + nb * (NB * NB + RD_STRIDE) * 4 + (size_t)32 * NB * K * 4 + 256;
 }
 
 extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
@@ -363,7 +363,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     float* Rd = T + (size_t)NB * K;
     float* Dinv = Rd + (size_t)nblk * RD_STRIDE;
     float* split_ws = Dinv + (size_t)nblk * NB * NB;
-    const size_t split_ws_bytes = (size_t)16 * NB * K * 4;
+    const size_t split_ws_bytes = (size_t)32 * NB * K * 4;
     float* Y = U;
     const size_t inv_lds = (size_t)(NB * LDT + NB * LDP) * sizeof(float);
     const size_t potf2_lds = (size_t)(NB * LDA + 4 * 32 * 32) * sizeof(float);

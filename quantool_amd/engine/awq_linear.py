@@ -1,0 +1,89 @@
+"""Per-mapping AWQ on the device (upstream AWQModifier, reached through
+``src/quantool/methods/llm_compressor/awq/awq.py:81`` / ``base.py:161``).
+
+Single-consumer mappings (the parent module is the balance Linear(s) themselves -- v->o, up->down and
+the synthetic per-Linear mode): the 20-point grid loss is evaluated through the
+Gram matrix (``awq.hip`` header), then the best scales are applied and the weights quantised by plain
+round-to-nearest with the standard observer (/7.5), as upstream does after smoothing.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+
+from ..hip import ops
+from .schemes import QuantArgs
+
+
+@dataclass
+class AWQResult:
+    weight_packed: Optional[torch.Tensor]
+    weight_q: Optional[torch.Tensor]
+    weight_scale: torch.Tensor
+    weight_zero_point: Optional[torch.Tensor]
+    weight_g_idx: Optional[torch.Tensor]
+    weight_shape: torch.Tensor
+    smoothing_scales: torch.Tensor            # fp32 [K]: W_balance *= s, previous op /= s
+    best_ratio_idx: torch.Tensor              # int64 [] device
+    losses: torch.Tensor                      # fp32 [n_grid] device
+    scaled_weight: torch.Tensor = field(repr=False, default=None)   # W * s in model dtype
+    scale_f32: torch.Tensor = field(repr=False, default=None)
+    zp_f32: torch.Tensor = field(repr=False, default=None)
+
+
+def awq_search(weights: Sequence[torch.Tensor], batches: Iterable[torch.Tensor], qargs: QuantArgs, *,
+               n_grid: int = 20, duo_scaling: bool = True, device=None):
+    """Returns (scales[n_grid, K], losses[n_grid], best index tensor, n_tokens)."""
+    K = weights[0].shape[1]
+    dev = device or weights[0].device
+    gs = qargs.kernel_group_size
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    x_sum = torch.zeros(K, dtype=torch.float32, device=dev)
+    n_tokens = 0
+    for xb in batches:
+        xb = xb.to(dev)
+        if xb.dtype != torch.bfloat16:
+            xb = xb.to(torch.bfloat16)
+        ops.xtx_accumulate(xb, G)
+        ops.act_stats_accumulate(xb, abs_sum=x_sum)
+        n_tokens += xb.numel() // K
+    ops.symmetrize_lower(G)
+    w_sum = torch.zeros(K, dtype=torch.float32, device=dev)
+    n_rows = 0
+    for w in weights:
+        ops.awq_weight_mean_accumulate(w, gs, w_sum)
+        n_rows += w.shape[0]
+    scales = ops.awq_scales(x_sum, n_tokens, w_sum, n_rows, n_grid, duo_scaling)
+    # the loss of a mapping is the mean over ALL balance layers' outputs = row-weighted mean
+    losses = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+    tmp = torch.zeros(1, dtype=torch.float32, device=dev)
+    for gi in range(n_grid):
+        for w in weights:
+            ops.awq_loss(w, scales[gi], gs, qargs.symmetric, qargs.num_bits, G, n_tokens, tmp)
+            losses[gi] += tmp[0] * (w.shape[0] / n_rows)
+    best = torch.argmin(losses)
+    return scales, losses, best, n_tokens
+
+
+def awq_quantize_group(weights: Sequence[torch.Tensor], batches: Iterable[torch.Tensor], qargs: QuantArgs, *,
+                       n_grid: int = 20, duo_scaling: bool = True, device=None) -> List[AWQResult]:
+    scales, losses, best, _ = awq_search(weights, batches, qargs, n_grid=n_grid, duo_scaling=duo_scaling,
+                                         device=device)
+    s = scales[best].contiguous()
+    gs = qargs.kernel_group_size
+    out: List[AWQResult] = []
+    for w in weights:
+        R, K = w.shape
+        ws = ops.scale_columns(w, s)                                        # W_balance *= s (model dtype)
+        scale, zp, _, _ = ops.group_minmax_qparams(ws, gs, qargs.symmetric, qargs.num_bits)
+        Qt = ops.rtn_quantize(ws, scale, zp, gs, qargs.num_bits)
+        packed = ops.pack_int4(Qt) if qargs.num_bits == 4 else None
+        sdt = w.dtype if w.dtype in (torch.bfloat16, torch.float16) else torch.float32
+        out.append(AWQResult(
+            weight_packed=packed, weight_q=None if packed is not None else Qt.t().contiguous(),
+            weight_scale=scale.to(sdt), weight_zero_point=None if qargs.symmetric else zp.to(torch.int8),
+            weight_g_idx=None, weight_shape=torch.tensor([R, K], dtype=torch.int64), smoothing_scales=s,
+            best_ratio_idx=best, losses=losses, scaled_weight=ws, scale_f32=scale, zp_f32=zp))
+    return out

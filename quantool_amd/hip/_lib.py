@@ -43,6 +43,22 @@ SIGNATURES = {
     "qt_gptq_sweep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "qt_pack_int4": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "qt_awq_weight_mean_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "qt_awq_weight_mean_accumulate": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_void_p,
+                                              c_size_t, c_void_p]),
+    "qt_awq_scales": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "qt_symmetrize_lower": (c_int, [c_void_p, c_int, c_void_p]),
+    "qt_awq_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "qt_awq_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64,
+                            c_void_p, c_void_p, c_size_t, c_void_p]),
+    "qt_scale_columns": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_int64,
+                                 c_void_p]),
+    "qt_rtn_quantize": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_void_p, c_void_p]),
+    "qt_col_absmax_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "qt_col_absmax_accumulate": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t,
+                                         c_void_p]),
+    "qt_smoothquant_scales": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "qt_profile_enable": (c_int, [c_int]),
     "qt_profile_read": (c_int, [c_int, c_void_p, c_void_p]),
     "qt_dequantize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -256,3 +256,104 @@ def dequantize(Qt: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, g_of_col
                                              g_of_col.data_ptr(), out.data_ptr(), _dtype_code(out), out.stride(0),
                                              _stream()))
     return out
+
+
+# ---- a12  AWQ ------------------------------------------------------------------------------
+def _w2d(W: torch.Tensor):
+    if W.dim() != 2 or not W.is_cuda or W.stride(1) != 1:
+        raise ValueError("W must be a 2-d device tensor with unit column stride")
+    return W.shape
+
+
+def awq_weight_mean_accumulate(W: torch.Tensor, group_size: int, w_sum: torch.Tensor) -> None:
+    lib = load()
+    R, K = _w2d(W)
+    _req(w_sum, torch.float32, "w_sum", 1)
+    assert w_sum.numel() == K and w_sum.is_contiguous()
+    ws = workspace(lib.qt_awq_weight_mean_workspace_bytes(R, K), W.device, "awq_wm")
+    check("qt_awq_weight_mean_accumulate", lib.qt_awq_weight_mean_accumulate(
+        W.data_ptr(), _dtype_code(W), R, K, W.stride(0), group_size, w_sum.data_ptr(), ws.data_ptr(), ws.numel(),
+        _stream()))
+
+
+def awq_scales(x_abs_sum: torch.Tensor, n_tokens: int, w_sum: torch.Tensor, n_rows: int, n_grid: int = 20,
+               duo_scaling: bool = True) -> torch.Tensor:
+    lib = load()
+    _req(x_abs_sum, torch.float32, "x_abs_sum", 1)
+    _req(w_sum, torch.float32, "w_sum", 1)
+    K = x_abs_sum.numel()
+    assert w_sum.numel() == K
+    out = torch.empty((n_grid, K), dtype=torch.float32, device=x_abs_sum.device)
+    check("qt_awq_scales", lib.qt_awq_scales(x_abs_sum.data_ptr(), int(n_tokens), w_sum.data_ptr(), int(n_rows), K,
+                                             n_grid, int(bool(duo_scaling)), out.data_ptr(), _stream()))
+    return out
+
+
+def symmetrize_lower(G: torch.Tensor) -> None:
+    lib = load()
+    _req(G, torch.float32, "G", 2)
+    assert G.is_contiguous() and G.shape[0] == G.shape[1]
+    check("qt_symmetrize_lower", lib.qt_symmetrize_lower(G.data_ptr(), G.shape[0], _stream()))
+
+
+def awq_loss(W: torch.Tensor, s: torch.Tensor, group_size: int, symmetric: bool, num_bits: int, Gfull: torch.Tensor,
+             n_tokens: int, out: torch.Tensor) -> None:
+    """out[0] (device fp32) = search loss for the per-channel scales s[K]."""
+    lib = load()
+    R, K = _w2d(W)
+    _req(s, torch.float32, "s", 1)
+    _req(Gfull, torch.float32, "Gfull", 2)
+    _req(out, torch.float32, "out")
+    assert s.numel() == K and s.is_contiguous() and Gfull.shape == (K, K) and Gfull.is_contiguous()
+    ws = workspace(lib.qt_awq_loss_workspace_bytes(R, K), W.device, "awq_loss")
+    check("qt_awq_loss", lib.qt_awq_loss(W.data_ptr(), _dtype_code(W), R, K, W.stride(0), s.data_ptr(), group_size,
+                                         int(bool(symmetric)), num_bits, Gfull.data_ptr(), int(n_tokens),
+                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+
+
+def scale_columns(W: torch.Tensor, s: torch.Tensor, divide: bool = False) -> torch.Tensor:
+    lib = load()
+    R, K = _w2d(W)
+    _req(s, torch.float32, "s", 1)
+    assert s.numel() == K and s.is_contiguous()
+    out = torch.empty((R, K), dtype=W.dtype, device=W.device)
+    check("qt_scale_columns", lib.qt_scale_columns(W.data_ptr(), _dtype_code(W), R, K, W.stride(0), s.data_ptr(),
+                                                   int(bool(divide)), out.data_ptr(), out.stride(0), _stream()))
+    return out
+
+
+def rtn_quantize(W: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, group_size: int, num_bits: int = 4):
+    """Plain round-to-nearest levels Qt[K, R] int8."""
+    lib = load()
+    R, K = _w2d(W)
+    _req(scale, torch.float32, "scale", 2)
+    _req(zp, torch.float32, "zp", 2)
+    G = scale.shape[1]
+    assert scale.shape == (R, G) and zp.shape == (R, G) and scale.is_contiguous() and zp.is_contiguous()
+    Qt = torch.empty((K, R), dtype=torch.int8, device=W.device)
+    check("qt_rtn_quantize", lib.qt_rtn_quantize(W.data_ptr(), _dtype_code(W), R, K, W.stride(0), scale.data_ptr(),
+                                                 zp.data_ptr(), G, group_size, num_bits, Qt.data_ptr(), _stream()))
+    return Qt
+
+
+# ---- a13  SmoothQuant ----------------------------------------------------------------------
+def col_absmax_accumulate(W: torch.Tensor, wmax: torch.Tensor) -> None:
+    lib = load()
+    R, K = _w2d(W)
+    _req(wmax, torch.float32, "wmax", 1)
+    assert wmax.numel() == K and wmax.is_contiguous()
+    ws = workspace(lib.qt_col_absmax_workspace_bytes(R, K), W.device, "absmax")
+    check("qt_col_absmax_accumulate", lib.qt_col_absmax_accumulate(W.data_ptr(), _dtype_code(W), R, K, W.stride(0),
+                                                                   wmax.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                                   _stream()))
+
+
+def smoothquant_scales(cmin: torch.Tensor, cmax: torch.Tensor, wmax: torch.Tensor, alpha: float) -> torch.Tensor:
+    lib = load()
+    for n, t in (("cmin", cmin), ("cmax", cmax), ("wmax", wmax)):
+        _req(t, torch.float32, n, 1)
+    K = cmin.numel()
+    s = torch.empty(K, dtype=torch.float32, device=cmin.device)
+    check("qt_smoothquant_scales", lib.qt_smoothquant_scales(cmin.data_ptr(), cmax.data_ptr(), wmax.data_ptr(), K,
+                                                             float(alpha), s.data_ptr(), _stream()))
+    return s

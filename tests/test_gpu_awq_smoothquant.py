@@ -1,0 +1,102 @@
+"""AWQ scale search (a12) and SmoothQuant (a13) on the GPU vs the oracle."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import bits_to_bf16_tensor, synth_weight
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def test_awq_search_matches_oracle_fixture(dev, oracle):
+    from quantool_amd.engine.awq_linear import awq_quantize_group, awq_search
+    from quantool_amd.engine.schemes import QuantArgs
+
+    with np.load(GOLD / "awq_w4a16_32x256.npz", allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    W = torch.from_numpy(g["W"]).to(dev)
+    X = bits_to_bf16_tensor(g["X_bf16"], dev)
+    qa = QuantArgs()
+    scales, losses, best, n_tok = awq_search([W], [X[:300], X[300:]], qa)
+    torch.cuda.synchronize()
+    # x_mean / w_mean feed powf: scales agree to fp32 rounding of pow, not bit for bit
+    o_scales = np.stack([oracle.awq_scales_for_ratio(g["x_mean"], g["w_mean"], i / 20) for i in range(20)])
+    np.testing.assert_allclose(scales.cpu().numpy(), o_scales, rtol=1e-5)          # north_star: within 1e-5
+    # loss through the Gram matrix == direct fp64 loss (same algebra), tolerance from fp32 G
+    np.testing.assert_allclose(losses.cpu().numpy(), g["losses"], rtol=2e-3)
+    assert int(best.item()) == int(g["best_ratio_idx"])
+    res = awq_quantize_group([W], [X], qa)[0]
+    torch.cuda.synchronize()
+    s = res.smoothing_scales.cpu().numpy()
+    np.testing.assert_allclose(s, g["best_scales"], rtol=1e-5)
+    # final step: RTN with the standard observer on W*s -- exact given the GPU's own s
+    Ws = (g["W"] * s[None, :]).astype(np.float32)
+    sc, zp = oracle.minmax_qparams(Ws, 128, True, 4)
+    np.testing.assert_array_equal(res.scale_f32.cpu().numpy(), sc)
+    gcol = np.arange(256) // 128
+    q, _ = oracle.fake_quantize(Ws, sc[:, gcol], zp[:, gcol], 4)
+    np.testing.assert_array_equal(oracle.unpack_int4(res.weight_packed.cpu().numpy(), 256), q.astype(np.int8))
+
+
+def test_awq_two_balance_layers_and_asym(dev, oracle):
+    from quantool_amd.engine.awq_linear import awq_search
+    from quantool_amd.engine.schemes import QuantArgs
+
+    rng = np.random.default_rng(3)
+    K, N = 384, 640
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    X[:, :5] *= 15
+    xb = oracle.f32_to_bf16_bits(X)
+    W1, W2 = synth_weight(48, K, 1, 0.05), synth_weight(16, K, 2, 0.05)
+    r = oracle.awq_best_scale(xb, [W1, W2], 128, symmetric=False)
+    scales, losses, best, _ = awq_search([torch.from_numpy(W1).to(dev), torch.from_numpy(W2).to(dev)],
+                                         [bits_to_bf16_tensor(xb, dev)], QuantArgs(symmetric=False))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses.cpu().numpy(), r["losses"], rtol=3e-3)
+    assert int(best.item()) == r["best_ratio_idx"]
+
+
+def test_smoothquant_scales_and_apply(dev, oracle):
+    from quantool_amd.engine.smoothquant import ChannelMinMax, apply_smoothing, smoothquant_scales
+
+    rng = np.random.default_rng(4)
+    K, N = 264, 500
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    X[:, 7] *= 20
+    xb = oracle.f32_to_bf16_bits(X)
+    W1, W2 = synth_weight(40, K, 5, 0.05), synth_weight(24, K, 6, 0.05)
+    W1[:, 3] = 0
+    W2[:, 3] = 0                                  # w == 0 -> s = a
+    st = ChannelMinMax(K, dev)
+    Xd = bits_to_bf16_tensor(xb, dev)
+    st.add(Xd[:200])
+    st.add(Xd[200:])
+    t1, t2 = torch.from_numpy(W1).to(dev), torch.from_numpy(W2).to(dev)
+    s = smoothquant_scales(st, [t1, t2], 0.5)
+    torch.cuda.synchronize()
+    amin, amax = oracle.channel_minmax(xb)
+    want = oracle.smoothquant_scales(amin, amax, [W1, W2], 0.5)
+    np.testing.assert_allclose(s.cpu().numpy(), want, rtol=1e-5)
+    assert s[3].item() == pytest.approx(float(amax[3] - amin[3]))
+    norm_w = torch.ones(K, dtype=torch.float32, device=dev)
+    (n1, n2), (nv,) = apply_smoothing(s, [t1, t2], [norm_w])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(n1.cpu().numpy(), W1 * s.cpu().numpy()[None, :])
+    np.testing.assert_array_equal(nv.cpu().numpy(), (1.0 / s.cpu().numpy()).astype(np.float32))
+
+
+def test_rtn_matches_sweep_with_identity_factor(dev, oracle):
+    from quantool_amd.hip import ops
+
+    Wn = synth_weight(70, 256, 9)
+    W = torch.from_numpy(Wn).to(dev)
+    scale, zp, st, zt = ops.group_minmax_qparams(W, 128, False, 4)
+    Qt = ops.rtn_quantize(W, scale, zp, 128, 4)
+    U = torch.eye(256, dtype=torch.float32, device=dev)
+    g_idx = (torch.arange(256, device=dev) // 128).to(torch.int32)
+    Qt2, _ = ops.gptq_sweep(W.clone(), U, st, zt, g_idx, 128, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(Qt, Qt2)

@@ -1,0 +1,96 @@
+"""N1: the sequential decoder-layer driver on a tiny random-init Llama (no download), through the
+``gptq`` plugin, and the compressed-tensors layout it saves."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_llama(dev):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=512, max_position_embeddings=128, tie_word_embeddings=False)
+    torch.manual_seed(0)
+    return LlamaForCausalLM(cfg).to(torch.bfloat16).to(dev)
+
+
+def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
+    import quantool_amd.methods  # noqa: F401
+    from quantool_amd.core import QuantizerRegistry
+    from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
+    from quantool_amd.engine.schemes import QuantArgs
+    from safetensors.torch import load_file
+
+    monkeypatch.chdir(tmp_path)
+    model = _tiny_llama(dev)
+    ref = _tiny_llama(dev)   # same seed -> same weights
+    g = torch.Generator().manual_seed(1)
+    data = [{"input_ids": torch.randint(0, 512, (48,), generator=g)} for _ in range(8)]
+
+    # expected layer-0 attention-input group, computed directly on the hooked activations
+    acc = HessianAccumulator(256, dev)
+    l0 = ref.model.layers[0]
+    hk = l0.self_attn.q_proj.register_forward_pre_hook(lambda m, a: acc.add(a[0]))
+    with torch.no_grad():
+        for row in data:
+            ref(input_ids=row["input_ids"].reshape(1, -1).to(dev), use_cache=False)
+    hk.remove()
+    want = gptq_quantize_shared([l0.self_attn.q_proj.weight.data, l0.self_attn.k_proj.weight.data,
+                                 l0.self_attn.v_proj.weight.data], acc, QuantArgs(actorder="static"))
+
+    q = QuantizerRegistry.create("gptq", model_id="synthetic/tiny-llama")
+    out = q.quantize(model=model, level="W4A16", dataset=data, num_calibration_samples=8, max_seq_length=64,
+                     shuffle_calibration_samples=False)
+    torch.cuda.synchronize()
+    assert q.last_model is model
+    sd = load_file(str(Path(out) / "model.safetensors"))
+    for lname in ("q_proj", "k_proj", "v_proj"):
+        key = f"model.layers.0.self_attn.{lname}"
+        assert f"{key}.weight" not in sd and f"{key}.weight_packed" in sd
+    assert torch.equal(sd["model.layers.0.self_attn.q_proj.weight_packed"], want[0].weight_packed.cpu())
+    assert torch.equal(sd["model.layers.0.self_attn.k_proj.weight_packed"], want[1].weight_packed.cpu())
+    assert "lm_head.weight" in sd and "lm_head.weight_packed" not in sd          # ignored
+    assert "model.embed_tokens.weight" in sd
+    n_q = sum(1 for k in sd if k.endswith("weight_packed"))
+    assert n_q == 2 * 7
+    # weights were replaced by dequantised values on the int4 grid
+    w = model.model.layers[1].mlp.down_proj.weight.data.float().cpu().numpy()
+    r = model._qt_results["model.layers.1.mlp.down_proj"]
+    np.testing.assert_array_equal(
+        w, oracle.bf16_bits_to_f32(oracle.f32_to_bf16_bits(r.dequantized().cpu().numpy())))
+    # layer 1 was calibrated on the outputs of the QUANTISED layer 0 (sequential), so its packed
+    # q_proj differs from what un-quantised layer-0 outputs would give -- just check it is populated
+    assert sd["model.layers.1.self_attn.q_proj.weight_packed"].abs().sum() > 0
+    cfg = json.loads((Path(out) / "config.json").read_text())
+    assert cfg["quantization_config"]["format"] == "pack-quantized"
+    assert cfg["hidden_size"] == 256
+
+
+def test_smoothquant_plus_gptq_on_tiny_llama(dev, tmp_path, monkeypatch):
+    import quantool_amd.methods  # noqa: F401
+    from quantool_amd.core import QuantizerRegistry
+
+    monkeypatch.chdir(tmp_path)
+    model = _tiny_llama(dev)
+    x = torch.randint(0, 512, (1, 32), device=dev)
+    with torch.no_grad():
+        before = model(input_ids=x).logits.float()
+    norm_before = model.model.layers[0].input_layernorm.weight.data.clone()
+    g = torch.Generator().manual_seed(2)
+    data = [{"input_ids": torch.randint(0, 512, (40,), generator=g)} for _ in range(6)]
+    q = QuantizerRegistry.create("smoothquant", model_id="synthetic/tiny-llama")
+    q.quantize(model=model, level="W8A8", dataset=data, num_calibration_samples=6, max_seq_length=64)
+    torch.cuda.synchronize()
+    assert not torch.equal(model.model.layers[0].input_layernorm.weight.data, norm_before)   # norm /= s
+    r = model._qt_results["model.layers.0.self_attn.q_proj"]
+    assert r.weight_packed is None and r.weight_q.dtype == torch.int8 and r.weight_scale.shape == (256, 1)
+    with torch.no_grad():
+        after = model(input_ids=x).logits.float()
+    # int8 channel-wise + smoothing keeps the function close
+    rel = (after - before).norm() / before.norm()
+    assert rel < 0.1, rel
