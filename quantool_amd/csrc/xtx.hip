@@ -9,6 +9,9 @@
 // Work decomposition: lower-triangular 256x256 output tiles x S token chunks.  Every workgroup
 // writes its fp32 partial tile to a slab; xtx_reduce_kernel sums the S slabs of a tile in fixed
 // order and adds them into G (deterministic; no atomics).
+#include <map>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -31,6 +34,7 @@ struct XtxParams {
     int n_tiles;    // lower-triangular 256x256 tiles
     int n_splits;   // S
     float* slabs;   // [S][n_tiles][256*256]
+    const int* tile_tab;  // [n_tiles] (ti << 16) | tj, in L2-friendly super-tile order
 };
 
 __device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
@@ -42,23 +46,28 @@ __device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
 }
 
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // Two DISTINCT LDS objects (not one array with two halves): hipcc then knows that the
+    // ds_reads of one stage cannot alias the in-flight LDS-DMA writes of the other and stops
+    // inserting s_waitcnt vmcnt(0) in front of every stage's first read (which serialised the
+    // prefetch of tile t+1 with the compute of tile t).
+    __shared__ __attribute__((aligned(16))) char stage0[STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char stage1[STAGE_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
 
     // XCD-aware remap (bijective form): workgroups that share an XCD get consecutive logical
-    // ids = neighbouring tiles of the same token chunk, so their X panels hit that XCD's L2.
+    // ids = consecutive entries of the tile table for one token chunk.  The table walks the
+    // lower triangle in 4x8 super-tiles, so the 32 workgroups resident on an XCD touch ~12
+    // distinct X panels per K-step instead of ~33: the rest are hits in that XCD's L2.
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int chunk = logical / p.n_tiles;
     const int tile = logical - chunk * p.n_tiles;
-    int ti = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    while (ti * (ti + 1) / 2 > tile) --ti;
-    const int tj = tile - ti * (ti + 1) / 2;
+    const int tt_packed = p.tile_tab[tile];
+    const int ti = tt_packed >> 16, tj = tt_packed & 0xFFFF;
     const bool diag = (ti == tj);
 
     const int base_cnt = p.n_tt / p.n_splits, rem = p.n_tt % p.n_splits;
@@ -71,11 +80,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     const int lch = pch ^ ((row_lo & 3) << 2);          // logical chunk (source-side swizzle)
     const int K = p.K;
 
-    auto stage = [&](int buf, int tt) {
+    auto stage = [&](char* sbase, int tt) {
         const bool is_tail = p.has_tail && (tt == p.n_tt - 1);
         const __bf16* src = is_tail ? p.tail : p.X + (size_t)tt * BKT * (size_t)p.ldx;
         const size_t ld = is_tail ? (size_t)K : (size_t)p.ldx;
-        char* sbase = smem + buf * STAGE_BYTES;
         const int nops = diag ? 1 : 2;
         for (int op = 0; op < nops; ++op) {
             const int c0 = (op == 0 ? ti : tj) * BT;
@@ -110,8 +118,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    auto compute = [&](int buf) {
-        const char* abase = smem + buf * STAGE_BYTES;
+    auto compute = [&](const char* abase) {
         const char* bbase = diag ? abase : abase + OP_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -129,17 +136,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     };
 
     if (cnt > 0) {
-        stage(0, tt0);
+        stage(stage0, tt0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int cur = 0;
-        for (int t = 0; t < cnt; ++t) {
-            if (t + 1 < cnt) stage(cur ^ 1, tt0 + t + 1);
-            compute(cur);
+        int t = 0;
+        for (; t + 1 < cnt; t += 2) {
+            stage(stage1, tt0 + t + 1);
+            compute(stage0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            cur ^= 1;
+            if (t + 2 < cnt) stage(stage0, tt0 + t + 2);
+            compute(stage1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
+        if (t < cnt) compute(stage0);
     }
 
     // ---- epilogue: fp32 partial tile -> slab (row-major 256x256) ----
@@ -159,12 +170,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
 
 // G[tile] += sum_s slab[s][tile]  (ascending s; one float4 per thread per step)
 __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ slabs, int n_tiles,
-                                                         int n_splits, float* __restrict__ G, int K) {
+                                                         int n_splits, float* __restrict__ G, int K,
+                                                         const int* __restrict__ tile_tab) {
     const int tile = blockIdx.x;
-    int ti = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    while (ti * (ti + 1) / 2 > tile) --ti;
-    const int tj = tile - ti * (ti + 1) / 2;
+    const int tt_packed = tile_tab[tile];
+    const int ti = tt_packed >> 16, tj = tt_packed & 0xFFFF;
     const int part = blockIdx.y;  // 16 parts of 16 rows
     const size_t tile_elems = (size_t)BT * BT;
     for (int e = threadIdx.x; e < 16 * (BT / 4); e += blockDim.x) {
@@ -191,8 +201,17 @@ __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict
 
 struct XtxPlan {
     int n_tiles, n_tt, has_tail, n_splits;
-    size_t slab_bytes, tail_bytes;
+    size_t slab_bytes, tail_bytes, tab_bytes;
 };
+
+// lower-triangular tiles in 4 (rows) x 8 (cols) super-tile order
+void xtx_tile_order(int nt, std::vector<int>& tab) {
+    tab.clear();
+    for (int bi = 0; bi < nt; bi += 4)
+        for (int bj = 0; bj <= bi + 3 && bj < nt; bj += 8)
+            for (int ti = bi; ti < bi + 4 && ti < nt; ++ti)
+                for (int tj = bj; tj < bj + 8 && tj <= ti; ++tj) tab.push_back((ti << 16) | tj);
+}
 
 XtxPlan xtx_plan(int64_t n_tokens, int K) {
     XtxPlan pl;
@@ -218,6 +237,7 @@ XtxPlan xtx_plan(int64_t n_tokens, int K) {
     pl.n_splits = best;
     pl.slab_bytes = (size_t)pl.n_splits * pl.n_tiles * BT * BT * 4;
     pl.tail_bytes = pl.has_tail ? qt_align_up((size_t)BKT * K * 2, 256) : 0;
+    pl.tab_bytes = qt_align_up((size_t)pl.n_tiles * 4, 256);
     return pl;
 }
 
@@ -226,7 +246,7 @@ XtxPlan xtx_plan(int64_t n_tokens, int K) {
 extern "C" size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K) {
     if (n_tokens <= 0 || K <= 0) return 0;
     XtxPlan pl = xtx_plan(n_tokens, K);
-    return pl.slab_bytes + pl.tail_bytes + 256;
+    return pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
 }
 
 extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G,
@@ -239,7 +259,7 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     QT_CHECK_ARG(X && G, "qt_xtx_accumulate: null pointer");
     QT_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)G & 15) == 0, "qt_xtx_accumulate: X and G must be 16-byte aligned");
     XtxPlan pl = xtx_plan(n_tokens, K);
-    const size_t need = pl.slab_bytes + pl.tail_bytes + 256;
+    const size_t need = pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
     if (workspace_bytes < need || !workspace) {
         qt_set_error("qt_xtx_accumulate: workspace %zu < required %zu", workspace_bytes, need);
         return QT_ERR_WORKSPACE;
@@ -247,17 +267,24 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
     float* slabs = (float*)ws;
     __bf16* tail = pl.has_tail ? (__bf16*)(ws + pl.slab_bytes) : nullptr;
+    int* tile_tab = (int*)(ws + pl.slab_bytes + pl.tail_bytes);
+    {
+        // host copy kept alive for the life of the process (the async copy reads it)
+        static std::map<int, std::vector<int>> tabs;
+        std::vector<int>& tab = tabs[K];
+        if (tab.empty()) xtx_tile_order((K + BT - 1) / BT, tab);
+        if ((int)tab.size() != pl.n_tiles) {
+            qt_set_error("qt_xtx_accumulate: internal tile table size mismatch");
+            return QT_ERR_INVALID;
+        }
+        QT_HIP(hipMemcpyAsync(tile_tab, tab.data(), (size_t)pl.n_tiles * 4, hipMemcpyHostToDevice, stream));
+    }
     if (pl.has_tail) {
         const int64_t full = n_tokens / BKT * BKT;
         const int64_t tail_rows = n_tokens - full;
         QT_HIP(hipMemsetAsync(tail, 0, (size_t)BKT * K * 2, stream));
         QT_HIP(hipMemcpy2DAsync(tail, (size_t)K * 2, (const char*)X + (size_t)full * ldx * 2, (size_t)ldx * 2,
                                 (size_t)K * 2, (size_t)tail_rows, hipMemcpyDeviceToDevice, stream));
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        QT_HIP(hipFuncSetAttribute((const void*)xtx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
     }
     XtxParams p;
     p.X = (const __bf16*)X;
@@ -269,12 +296,13 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     p.n_tiles = pl.n_tiles;
     p.n_splits = pl.n_splits;
     p.slabs = slabs;
+    p.tile_tab = tile_tab;
     qt_prof_mark(QT_PROF_XTX, stream);
-    hipLaunchKernelGGL(xtx_kernel, dim3(pl.n_tiles * pl.n_splits), dim3(NTHREADS), LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(xtx_kernel, dim3(pl.n_tiles * pl.n_splits), dim3(NTHREADS), 0, stream, p);
     qt_prof_mark(QT_PROF_XTX, stream);
     QT_LAUNCH_CHECK();
     hipLaunchKernelGGL(xtx_reduce_kernel, dim3(pl.n_tiles, 16), dim3(256), 0, stream, slabs, pl.n_tiles,
-                       pl.n_splits, G, K);
+                       pl.n_splits, G, K, (const int*)tile_tab);
     QT_LAUNCH_CHECK();
     return QT_OK;
 }
