@@ -165,8 +165,8 @@ def cpu_baseline_port(seconds_budget: float = 30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
@@ -254,7 +254,7 @@ def main():
     roofline = {
         "kernel": "xtx_kernel", "bound": "mfma", "achieved": round(achieved_tflops, 2),
         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
-        "traffic": None,
+        "traffic": pmc_traffic(),
         "launches": int(launches.value), "avg_launch_ms": round(tot_ms.value / max(1, launches.value), 4),
         "share_of_step_time": round(tot_ms.value * 1e-3 / elapsed, 4),
         "hbm_GBps_algorithmic": round(alg_bytes / (tot_ms.value * 1e-3) / 1e9, 1) if tot_ms.value > 0 else 0.0,
@@ -285,6 +285,16 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per xtx_kernel launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes
+    over this same workload, committed under profiles/); bench.py cannot run the profiler itself."""
+    f = ROOT / "profiles" / "r01_xtx_pmc_traffic.json"
+    try:
+        return float(json.loads(f.read_text())["avg_bytes_per_launch_over_a_step"])
+    except Exception:
+        return None
 
 
 def _lib_const(name: str) -> int:

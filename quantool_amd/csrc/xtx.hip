@@ -9,6 +9,8 @@
 // Work decomposition: lower-triangular 256x256 output tiles x S token chunks.  Every workgroup
 // writes its fp32 partial tile to a slab; xtx_reduce_kernel sums the S slabs of a tile in fixed
 // order and adds them into G (deterministic; no atomics).
+#include <stdlib.h>
+
 #include <map>
 #include <vector>
 
@@ -35,6 +37,8 @@ struct XtxParams {
     int n_splits;   // S
     float* slabs;   // [S][n_tiles][256*256]
     const int* tile_tab;  // [n_tiles] (ti << 16) | tj, in L2-friendly super-tile order
+    int map_mode;         // workgroup -> (chunk, tile) mapping (see kernel)
+    int tiles_per_xcd;
 };
 
 __device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
@@ -62,10 +66,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     // lower triangle in 4x8 super-tiles, so the 32 workgroups resident on an XCD touch ~12
     // distinct X panels per K-step instead of ~33: the rest are hits in that XCD's L2.
     const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int chunk = logical / p.n_tiles;
-    const int tile = logical - chunk * p.n_tiles;
+    int chunk, tile;
+    if (p.map_mode == 2) {
+        // all 8 XCDs walk the token chunks together, each over its own contiguous slice of the
+        // tile table: a panel missed by one XCD's L2 is a MALL hit for the other seven
+        const int xcd = orig & 7, pos = orig >> 3;
+        chunk = pos / p.tiles_per_xcd;
+        tile = xcd * p.tiles_per_xcd + (pos - chunk * p.tiles_per_xcd);
+        if (tile >= p.n_tiles || chunk >= p.n_splits) return;
+    } else if (p.map_mode == 1) {
+        chunk = orig / p.n_tiles;
+        tile = orig - chunk * p.n_tiles;
+    } else {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+        const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        chunk = logical / p.n_tiles;
+        tile = logical - chunk * p.n_tiles;
+    }
     const int tt_packed = p.tile_tab[tile];
     const int ti = tt_packed >> 16, tj = tt_packed & 0xFFFF;
     const bool diag = (ti == tj);
@@ -118,20 +135,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
+    // Software-pipelined fragment reads: the 12 transposing reads of k-step ks+1 are issued
+    // BEFORE the 8 MFMAs of k-step ks (256 MFMA cycles cover the LDS latency) and waited for with
+    // a counted lgkmcnt after them; sched_barrier pins that order against hipcc's scheduler.
     auto compute = [&](const char* abase) {
         const char* bbase = diag ? abase : abase + OP_BYTES;
+        bf16x8 a[2][4], b[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a[0][mi] = tr_load8(abase + aoff[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[0][ni] = tr_load8(bbase + boff[ni]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 a[4], b[2];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 4) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = tr_load8(abase + aoff[mi] + ks * 4096);
+                for (int mi = 0; mi < 4; ++mi) a[nxt][mi] = tr_load8(abase + aoff[mi] + (ks + 1) * 4096);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = tr_load8(bbase + boff[ni] + ks * 4096);
+                for (int ni = 0; ni < 2; ++ni) b[nxt][ni] = tr_load8(bbase + boff[ni] + (ks + 1) * 4096);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -297,8 +328,16 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     p.n_splits = pl.n_splits;
     p.slabs = slabs;
     p.tile_tab = tile_tab;
+    static int map_mode = -1;
+    if (map_mode < 0) {
+        const char* e = getenv("QT_XTX_MAP");
+        map_mode = e ? atoi(e) : 0;
+    }
+    p.map_mode = map_mode;
+    p.tiles_per_xcd = (pl.n_tiles + 7) / 8;
+    const int grid = (map_mode == 2) ? 8 * p.tiles_per_xcd * pl.n_splits : pl.n_tiles * pl.n_splits;
     qt_prof_mark(QT_PROF_XTX, stream);
-    hipLaunchKernelGGL(xtx_kernel, dim3(pl.n_tiles * pl.n_splits), dim3(NTHREADS), 0, stream, p);
+    hipLaunchKernelGGL(xtx_kernel, dim3(grid), dim3(NTHREADS), 0, stream, p);
     qt_prof_mark(QT_PROF_XTX, stream);
     QT_LAUNCH_CHECK();
     hipLaunchKernelGGL(xtx_reduce_kernel, dim3(pl.n_tiles, 16), dim3(256), 0, stream, slabs, pl.n_tiles,
