@@ -160,6 +160,16 @@ int qt_col_absmax_accumulate(const void* W, int w_dtype, int R, int K, int64_t l
 int qt_smoothquant_scales(const float* cmin, const float* cmax, const float* wmax, int K, float alpha,
                           float* s, qt_stream_t stream);
 
+/* ---- fp32 "TN" GEMM on the f32 MFMA (building block of a8 and a11; exposed for tests) ----------
+ * acc[m][n] = sum_{k ascending} A[k*lda + m] * B[k*ldb + n]   (bit-for-bit an fmaf chain from 0)
+ * mode 0: Cout = Cin - acc   1: Cout = acc   2: Cout = -acc.   skip_zero_k: B[k][n] == 0 for k < n.
+ * allow_split_k != 0 lets latency-bound shapes split k over workgroups (ordered slab reduction:
+ * deterministic, but no longer the single ascending chain -- the sweep never allows it). */
+size_t qt_sgemm_tn_f32_workspace_bytes(int M, int N);
+int qt_sgemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* Cin,
+                    int64_t ldcin, float* Cout, int64_t ldcout, int M, int N, int kdim, int skip_zero_k,
+                    int mode, int allow_split_k, void* workspace, size_t workspace_bytes, qt_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference surface) -------------
  * When enabled, HIP events are recorded on the launch stream immediately around the named
  * kernel; qt_profile_read synchronises them, returns the summed device time and the launch

@@ -260,3 +260,32 @@ int qt_sgemm_tn_dot(const SgemmArgs& a, hipStream_t stream, int* n_partial) {
     *n_partial = (int)((long)((a.M + 63) / 64) * ((a.N + 63) / 64));
     return launch<64, 64>(a, stream);
 }
+
+// C-ABI face of the fp32 TN GEMM (tests and micro-benchmarks; the hot path calls qt_sgemm_tn directly).
+extern "C" size_t qt_sgemm_tn_f32_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)32 * M * N * 4 + 256;
+}
+
+extern "C" int qt_sgemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* Cin,
+                               int64_t ldcin, float* Cout, int64_t ldcout, int M, int N, int kdim, int skip_zero_k,
+                               int mode, int allow_split_k, void* workspace, size_t workspace_bytes,
+                               qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(A && B && Cout && M > 0 && N > 0 && kdim >= 0, "qt_sgemm_tn_f32: bad arguments");
+    QT_CHECK_ARG(mode == SG_MODE_SUB || mode == SG_MODE_SET || mode == SG_MODE_NEG, "qt_sgemm_tn_f32: mode %d", mode);
+    QT_CHECK_ARG(mode != SG_MODE_SUB || Cin, "qt_sgemm_tn_f32: MODE_SUB needs Cin");
+    SgemmArgs g;
+    g.A = A; g.lda = lda;
+    g.B = B; g.ldb = ldb;
+    g.Cin = Cin; g.ldcin = ldcin;
+    g.Cout = Cout; g.ldcout = ldcout;
+    g.M = M; g.N = N; g.kdim = kdim;
+    g.k_mode = skip_zero_k ? SG_K_FROM_N0 : SG_K_FULL;
+    g.mode = mode;
+    if (allow_split_k && workspace) {
+        g.split_ws = (float*)qt_align_up((size_t)workspace, 256);
+        g.split_ws_bytes = workspace_bytes >= 256 ? workspace_bytes - 256 : 0;
+    }
+    return qt_sgemm_tn(g, stream);
+}

@@ -357,3 +357,23 @@ def smoothquant_scales(cmin: torch.Tensor, cmax: torch.Tensor, wmax: torch.Tenso
     check("qt_smoothquant_scales", lib.qt_smoothquant_scales(cmin.data_ptr(), cmax.data_ptr(), wmax.data_ptr(), K,
                                                              float(alpha), s.data_ptr(), _stream()))
     return s
+
+
+# ---- fp32 TN GEMM (tests / micro-benchmarks) ------------------------------------------------
+def sgemm_tn(A: torch.Tensor, B: torch.Tensor, Cin: Optional[torch.Tensor] = None, mode: int = 1,
+             skip_zero_k: bool = False, allow_split_k: bool = False, out: Optional[torch.Tensor] = None):
+    """acc = A^T B with A [k, M], B [k, N] fp32 row-major; mode 0: Cin - acc, 1: acc, 2: -acc."""
+    lib = load()
+    _req(A, torch.float32, "A", 2)
+    _req(B, torch.float32, "B", 2)
+    k, M = A.shape
+    k2, N = B.shape
+    assert k == k2 and A.stride(1) == 1 and B.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ws = workspace(lib.qt_sgemm_tn_f32_workspace_bytes(M, N) if allow_split_k else 1, A.device, "sgemm")
+    check("qt_sgemm_tn_f32", lib.qt_sgemm_tn_f32(
+        A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), _ptr(Cin), Cin.stride(0) if Cin is not None else 0,
+        out.data_ptr(), out.stride(0), M, N, k, int(skip_zero_k), mode, int(allow_split_k),
+        ws.data_ptr() if allow_split_k else None, ws.numel() if allow_split_k else 0, _stream()))
+    return out
