@@ -97,6 +97,22 @@ __global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {  // p is mo
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int h = lane >> 5, l31 = lane & 31;
+    // MODE_SUB reads C: issue those loads before the k-loop so their latency hides behind the
+    // MFMAs instead of heading the epilogue (short-k launches -- the sweep's trailing update has
+    // only 8 k-steps -- are otherwise epilogue-bound)
+    f32x16 cpre[WM][WN];
+    if (MODE == SG_MODE_SUB) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wave_m * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
+                    cpre[i][j][r] = (row < p.M && col < p.N) ? p.Cin[(size_t)row * p.ldcin + col] : 0.0f;
+                }
+    }
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
     if (nsteps > 0) {
         gload(k_begin);
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {  // p is mo
                 const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
                 if (row < p.M && col < p.N) {
                     float v = acc[i][j][r];
-                    if (MODE == SG_MODE_SUB) v = p.Cin[(size_t)row * p.ldcin + col] - v;
+                    if (MODE == SG_MODE_SUB) v = cpre[i][j][r] - v;
                     if (MODE == SG_MODE_NEG) v = -v;
                     p.Cout[(size_t)row * p.ldcout + col] = v;
                 }

@@ -168,18 +168,22 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                        if isinstance(m, nn.Linear) and gp.wants(f"{lname}.{n}", m)}
             if sq is not None:
                 _smooth_layer(layer, cache, sq.smoothing_strength, dev)
-            # discovery pass on batch 0: which Linears read the same tensor
-            seen: Dict[str, tuple] = {}
-            hooks = [m.register_forward_pre_hook(
-                (lambda name: lambda _m, a: seen.__setitem__(name, (a[0].data_ptr(), tuple(a[0].shape))))(n))
-                for n, m in linears.items()]
+            # discovery pass on batch 0: which Linears read the same tensor.  The input tensors are
+            # kept alive until the grouping is done: a freed activation's address can be handed to
+            # a later, unrelated tensor of the same shape, and pointer equality would then lie.
+            seen: Dict[str, torch.Tensor] = {}
+            hooks = [m.register_forward_pre_hook((lambda name: lambda _m, a: seen.__setitem__(name, a[0]))(n))
+                     for n, m in linears.items()]
             args, kwargs = cache[0]
             layer(*args, **kwargs)
             for hk in hooks:
                 hk.remove()
             groups: Dict[tuple, List[str]] = {}
             for n in linears:
-                groups.setdefault(seen[n], []).append(n)
+                t = seen[n]
+                key = (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()))
+                groups.setdefault(key, []).append(n)
+            seen.clear()
             leaders = {names[0]: names for names in groups.values()}
             accs = {lead: HessianAccumulator(linears[lead].in_features, dev) for lead in leaders}
             hooks = [linears[lead].register_forward_pre_hook(
@@ -222,20 +226,23 @@ def _smooth_layer(layer: nn.Module, cache, alpha: float, dev) -> None:
     if not norms:
         return
     stats: Dict[str, ChannelMinMax] = {}
-    out_ptr: Dict[str, int] = {}
+    out_ref: Dict[str, torch.Tensor] = {}   # holds each norm output alive so its address is not reused
     consumers: Dict[str, List[nn.Linear]] = {n: [] for n in norms}
 
     def norm_hook(name):
         def fn(_m, _a, out):
             st = stats.setdefault(name, ChannelMinMax(out.shape[-1], dev))
             st.add(out.reshape(-1, out.shape[-1]))
-            out_ptr[name] = out.data_ptr()
+            out_ref[name] = out
         return fn
 
     def lin_hook(mod):
         def fn(_m, a):
-            for n, p in out_ptr.items():
-                if a[0].data_ptr() == p and mod not in consumers[n]:
+            x = a[0]
+            for n, o in out_ref.items():
+                same = (x.untyped_storage().data_ptr() == o.untyped_storage().data_ptr()
+                        and x.storage_offset() == o.storage_offset() and x.shape == o.shape)
+                if same and mod not in consumers[n]:
                     consumers[n].append(mod)
         return fn
 
@@ -245,6 +252,7 @@ def _smooth_layer(layer: nn.Module, cache, alpha: float, dev) -> None:
         layer(*args, **kwargs)
     for hk in hooks:
         hk.remove()
+    out_ref.clear()
     for n, norm in norms.items():
         lins = consumers[n]
         if not lins or n not in stats:

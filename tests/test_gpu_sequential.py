@@ -58,6 +58,19 @@ def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
     assert "model.embed_tokens.weight" in sd
     n_q = sum(1 for k in sd if k.endswith("weight_packed"))
     assert n_q == 2 * 7
+    # o_proj reads a different tensor of the same shape as the hidden state: it must have got its
+    # own Hessian.  Within a layer every Linear is calibrated on the activations of the layer with
+    # its ORIGINAL weights (hooks pass first, quantisation after: SURVEY A.1 (i)-(ii)).
+    acc_o = HessianAccumulator(256, dev)
+    ref2 = _tiny_llama(dev)
+    hk2 = ref2.model.layers[0].self_attn.o_proj.register_forward_pre_hook(lambda m, a: acc_o.add(a[0]))
+    with torch.no_grad():
+        for row in data:
+            ref2(input_ids=row["input_ids"].reshape(1, -1).to(dev), use_cache=False)
+    hk2.remove()
+    want_o = gptq_quantize_shared([ref2.model.layers[0].self_attn.o_proj.weight.data], acc_o,
+                                  QuantArgs(actorder="static"))[0]
+    assert torch.equal(sd["model.layers.0.self_attn.o_proj.weight_packed"], want_o.weight_packed.cpu())
     # weights were replaced by dequantised values on the int4 grid
     w = model.model.layers[1].mlp.down_proj.weight.data.float().cpu().numpy()
     r = model._qt_results["model.layers.1.mlp.down_proj"]
