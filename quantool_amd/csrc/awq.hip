@@ -323,6 +323,7 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
     }
     float* Dt = (float*)qt_align_up((size_t)workspace, 256);
     float* partial = Dt + (size_t)R * K;
+    QT_CHECK_ARG(R <= 65535, "qt_awq_loss: R=%d > 65535 rows per call (split the balance layer)", R);
     hipLaunchKernelGGL(awq_diff_t_kernel, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s, gs, symmetric,
                        num_bits, Dt);
     QT_LAUNCH_CHECK();
@@ -346,9 +347,14 @@ extern "C" int qt_scale_columns(const void* W, int w_dtype, int R, int K, int64_
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && s && out && R > 0 && K > 0, "qt_scale_columns: bad arguments");
     QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_scale_columns: dtype");
-    hipLaunchKernelGGL(scale_columns_kernel, dim3((K + 255) / 256, R), dim3(256), 0, stream, W, w_dtype, R, K, ldw, s,
-                       divide, out, ldo);
-    QT_LAUNCH_CHECK();
+    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    for (int row0 = 0; row0 < R; row0 += 32768) {  // gridDim.y <= 65535
+        const int rows = (R - row0 < 32768) ? R - row0 : 32768;
+        hipLaunchKernelGGL(scale_columns_kernel, dim3((K + 255) / 256, rows), dim3(256), 0, stream,
+                           (const void*)((const char*)W + (size_t)row0 * ldw * esz), w_dtype, rows, K, ldw, s, divide,
+                           (void*)((char*)out + (size_t)row0 * ldo * esz), ldo);
+        QT_LAUNCH_CHECK();
+    }
     return QT_OK;
 }
 

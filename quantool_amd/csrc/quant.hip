@@ -163,9 +163,17 @@ extern "C" int qt_group_minmax_qparams(const void* W, int w_dtype, int R, int K,
     QT_CHECK_ARG(K % gs == 0, "qt_group_minmax_qparams: K=%d not divisible by group_size=%d", K, gs);
     float qmin, qmax;
     qt_range(num_bits, &qmin, &qmax);
-    hipLaunchKernelGGL(qparams_kernel, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, gs, symmetric,
-                       qmin, qmax, scale, zp, scale_t, zp_t);
-    QT_LAUNCH_CHECK();
+    // gridDim.y is limited to 65535: rows are processed in chunks (row0 offsets every pointer)
+    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    const int G = K / gs;
+    for (int row0 = 0; row0 < R; row0 += 32768) {
+        const int rows = (R - row0 < 32768) ? R - row0 : 32768;
+        hipLaunchKernelGGL(qparams_kernel, dim3(G, rows), dim3(64), 0, stream,
+                           (const void*)((const char*)W + (size_t)row0 * ldw * esz), w_dtype, R, K, ldw, gs, symmetric,
+                           qmin, qmax, scale + (size_t)row0 * G, zp + (size_t)row0 * G,
+                           scale_t ? scale_t + row0 : nullptr, zp_t ? zp_t + row0 : nullptr);
+        QT_LAUNCH_CHECK();
+    }
     return QT_OK;
 }
 
@@ -174,9 +182,14 @@ extern "C" int qt_weight_gather_f32(const void* W, int w_dtype, int R, int K, in
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && W_f32 && R > 0 && K > 0, "qt_weight_gather_f32: bad arguments");
     QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_weight_gather_f32: dtype %d unsupported", w_dtype);
-    hipLaunchKernelGGL(gather_f32_kernel, dim3((K + 255) / 256, R), dim3(256), 0, stream, W, w_dtype, R, K, ldw, perm,
-                       dead, W_f32);
-    QT_LAUNCH_CHECK();
+    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    for (int row0 = 0; row0 < R; row0 += 32768) {
+        const int rows = (R - row0 < 32768) ? R - row0 : 32768;
+        hipLaunchKernelGGL(gather_f32_kernel, dim3((K + 255) / 256, rows), dim3(256), 0, stream,
+                           (const void*)((const char*)W + (size_t)row0 * ldw * esz), w_dtype, rows, K, ldw, perm, dead,
+                           W_f32 + (size_t)row0 * K);
+        QT_LAUNCH_CHECK();
+    }
     return QT_OK;
 }
 
