@@ -60,7 +60,41 @@ __global__ __launch_bounds__(256) void diag_only_kernel(const float* __restrict_
     if (i < K) out[i] = G[(size_t)i * K + i] * c;
 }
 
+// a9: perm = argsort(diag, descending), stable (ties keep ascending index), by rank counting:
+// rank(i) = #{j : d[j] > d[i]  or  (d[j] == d[i] and j < i)};  perm[rank(i)] = i, inv[i] = rank(i).
+// O(K^2) compares on K <= 32768 values staged through LDS in chunks: ~1 ms at K = 28672, exact and
+// deterministic (no sort network, no atomics).
+__global__ __launch_bounds__(256) void argsort_rank_kernel(const float* __restrict__ d, int K,
+                                                           int32_t* __restrict__ perm, int32_t* __restrict__ inv) {
+    __shared__ float chunk[1024];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float di = (i < K) ? d[i] : 0.0f;
+    int rank = 0;
+    for (int c0 = 0; c0 < K; c0 += 1024) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 1024; e += 256) chunk[e] = (c0 + e < K) ? d[c0 + e] : -INFINITY;
+        __syncthreads();
+        const int lim = (K - c0 < 1024) ? K - c0 : 1024;
+        for (int e = 0; e < lim; ++e) {
+            const float dj = chunk[e];
+            rank += (dj > di) || (dj == di && (c0 + e) < i);
+        }
+    }
+    if (i < K) {
+        perm[rank] = i;
+        if (inv) inv[i] = rank;
+    }
+}
+
 }  // namespace
+
+extern "C" int qt_argsort_desc(const float* values, int K, int32_t* perm, int32_t* inv, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(values && perm && K > 0, "qt_argsort_desc: bad arguments");
+    hipLaunchKernelGGL(argsort_rank_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, values, K, perm, inv);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
 
 extern "C" size_t qt_hessian_prepare_workspace_bytes(int K) {
     (void)K;

@@ -109,9 +109,7 @@ def gptq_quantize_shared(weights: Sequence[torch.Tensor], acc: HessianAccumulato
     perm = inv = None
     if actorder is not None:
         diag = ops.hessian_diag(acc.G, acc.n)
-        perm = torch.argsort(diag, descending=True, stable=True).to(torch.int32)
-        inv = torch.empty_like(perm)
-        inv[perm.long()] = torch.arange(K, dtype=torch.int32, device=dev)
+        perm, inv = ops.argsort_desc(diag)
     ar = torch.arange(K, dtype=torch.int32, device=dev)
     g_orig = (ar // gsz).to(torch.int32)
 

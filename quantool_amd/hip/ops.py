@@ -113,6 +113,18 @@ def hessian_diag(G: torch.Tensor, n_samples: int) -> torch.Tensor:
     return out
 
 
+def argsort_desc(values: torch.Tensor):
+    """Stable descending argsort on the device: returns (perm int32[K], inv int32[K])."""
+    lib = load()
+    _req(values, torch.float32, "values", 1)
+    K = values.numel()
+    assert values.is_contiguous()
+    perm = torch.empty(K, dtype=torch.int32, device=values.device)
+    inv = torch.empty(K, dtype=torch.int32, device=values.device)
+    check("qt_argsort_desc", lib.qt_argsort_desc(values.data_ptr(), K, perm.data_ptr(), inv.data_ptr(), _stream()))
+    return perm, inv
+
+
 def hessian_prepare(G: torch.Tensor, n_samples: int, percdamp: float, perm: Optional[torch.Tensor] = None,
                     A_out: Optional[torch.Tensor] = None):
     """Returns (A flipped+damped [K,K] fp32 upper-valid, dead uint8[K], diag fp32[K])."""

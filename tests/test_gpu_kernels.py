@@ -112,6 +112,18 @@ def test_hessian_prepare(ops, oracle, dev, K, with_perm, with_dead):
     np.testing.assert_allclose(np.diag(got), np.diag(want), rtol=2.4e-7)
 
 
+@pytest.mark.parametrize("K", [1, 7, 1000, 4096, 14336])
+def test_argsort_desc_stable(ops, dev, K):
+    g = torch.Generator(device=dev).manual_seed(K)
+    v = torch.randn(K, generator=g, device=dev)
+    v[::5] = float(v[0])                              # plenty of exact ties
+    perm, inv = ops.argsort_desc(v)
+    torch.cuda.synchronize()
+    want = np.argsort(-v.cpu().numpy(), kind="stable").astype(np.int32)
+    np.testing.assert_array_equal(perm.cpu().numpy(), want)
+    np.testing.assert_array_equal(inv.cpu().numpy()[want], np.arange(K, dtype=np.int32))
+
+
 @pytest.mark.parametrize("K", [64, 128, 200, 384, 1024])
 def test_cholesky_inverse_upper(ops, oracle, dev, K):
     xb = synth_activations(4 * K, K, seed=K + 1)
