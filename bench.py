@@ -120,7 +120,7 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("QT_CPU_THREADS", "16"))))
 
 
-def cpu_baseline_port(seconds_budget: float = 30.0):
+def cpu_baseline_port():
     """The oracle (kind "port") on this box's host cores, on a bounded sample of the same
     workload: q_proj (4096 x 4096) -- Hessian accumulation in upstream's own form (per-sample
     fp32 `H += x.T @ x`) for 64 of the 512 samples (extrapolated x8, stated in `sample`), then
@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
+    ap.add_argument("--lanes", type=int, default=2, help="layers in flight (independent stream sets)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -220,7 +221,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kept.append(quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap,
-                                   lane=_ % 2))
+                                   lane=_ % max(1, args.lanes)))
     join_streams(dev)
     if dist is not None:
         # final gather of the packed state to rank 0 (the job's only collective)

@@ -8,7 +8,7 @@ section 8a rows a7-a11, a14), which quantool reaches through
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -106,7 +106,7 @@ def gptq_quantize_shared(weights: Sequence[torch.Tensor], acc: HessianAccumulato
     R = sum(rows)
 
     # ---- activation ordering (a9): perm = argsort(diag H, descending) --------------------
-    perm = inv = None
+    perm = inv = None   # perm: sweep position -> original column; inv: its inverse
     if actorder is not None:
         diag = ops.hessian_diag(acc.G, acc.n)
         perm, inv = ops.argsort_desc(diag)
