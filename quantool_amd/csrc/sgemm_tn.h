@@ -33,3 +33,7 @@ struct SgemmArgs {
 int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream);
 // MODE_DOT launch: one fp32 partial per workgroup into a.Cout; *n_partial = number written.
 int qt_sgemm_tn_dot(const SgemmArgs& a, hipStream_t stream, int* n_partial);
+
+// Ordered slab reduction (shared by the split-K paths): Cout = mode(Cin, sum_z slabs[z]).
+int qt_splitk_reduce(const float* slabs, int splits, int M, int N, const float* Cin, int64_t ldcin, float* Cout,
+                     int64_t ldcout, int mode, hipStream_t stream);

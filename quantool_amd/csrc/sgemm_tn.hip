@@ -230,6 +230,14 @@ int launch(const SgemmArgs& a, hipStream_t stream, int splits = 1) {
 
 }  // namespace
 
+int qt_splitk_reduce(const float* slabs, int splits, int M, int N, const float* Cin, int64_t ldcin, float* Cout,
+                     int64_t ldcout, int mode, hipStream_t stream) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N / 4 + 255) / 256 + 1, M), dim3(256), 0, stream, slabs, splits, M,
+                       N, Cin, ldcin, Cout, ldcout, mode);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
 int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return QT_OK;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);

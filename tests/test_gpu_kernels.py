@@ -124,7 +124,7 @@ def test_argsort_desc_stable(ops, dev, K):
     np.testing.assert_array_equal(inv.cpu().numpy()[want], np.arange(K, dtype=np.int32))
 
 
-@pytest.mark.parametrize("K", [64, 128, 200, 384, 1024])
+@pytest.mark.parametrize("K", [64, 128, 200, 384, 1024, 2048])
 def test_cholesky_inverse_upper(ops, oracle, dev, K):
     xb = synth_activations(4 * K, K, seed=K + 1)
     H = oracle.hessian_from_gram(oracle.gram_f64(xb), 8)
