@@ -85,9 +85,25 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0)
             st.wait_stream(main)
         else:
             st = main
+        xmode = os.environ.get("QT_BENCH_XTX_STREAM", "group") if overlap else "group"
+        if xmode in ("shared", "prio", "lane"):
+            # Gram passes on their own stream(s): "shared" = one for everything (they are the MFMA-bound
+            # kernels and gain nothing from running against each other), "lane" = one per layer in flight,
+            # "prio" = one per layer in flight at high stream priority
+            key = (dev.index, "xtx") if xmode == "shared" else (dev.index, "xtx", lane)
+            if key not in _STREAMS:
+                _STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1 if xmode == "prio" else 0)
+            sx = _STREAMS[key]
+            sx.wait_stream(main)
+            with torch.cuda.stream(sx):
+                acc = HessianAccumulator(K, dev)
+                acc.add(acts[gname], num_samples=n_samples)
+            acc.G.record_stream(st)
+            st.wait_stream(sx)
         with torch.cuda.stream(st):
-            acc = HessianAccumulator(K, dev)
-            acc.add(acts[gname], num_samples=n_samples)
+            if xmode == "group":
+                acc = HessianAccumulator(K, dev)
+                acc.add(acts[gname], num_samples=n_samples)
             res = gptq_quantize_shared([weights[n] for n, _ in lins], acc, qargs)
             for (lname, _), r in zip(lins, res):
                 outs[f"{lname}.weight_packed"] = r.weight_packed
@@ -98,7 +114,7 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0)
 
 def join_streams(dev):
     main = torch.cuda.current_stream(dev)
-    for key, st in _STREAMS.items():
+    for key, st in list(_STREAMS.items()):
         if key[0] == dev.index:
             main.wait_stream(st)
 
