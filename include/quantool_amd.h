@@ -141,7 +141,8 @@ int qt_awq_scales(const float* x_abs_sum, int64_t n_tokens, const float* w_sum, 
 /* Mirror the lower triangle of the Gram sum into the upper one (G full symmetric afterwards). */
 int qt_symmetrize_lower(float* G, int K, qt_stream_t stream);
 /* loss_out[0] (device fp32) = mean((X W^T - X Wq^T)^2) with Wq = pseudo_quant(W*s)/s, evaluated as
- * sum_r d_r G d_r^T / (n_tokens * R), D = W - Wq, G = X^T X full symmetric (see awq.hip header). */
+ * <G, D^T D>_F / (n_tokens * R), D = W - Wq rounded to bf16, G = X^T X (lower triangle read; see the
+ * awq.hip header). */
 size_t qt_awq_loss_workspace_bytes(int R, int K);
 int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
                 int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, float* loss_out,

@@ -3,9 +3,11 @@
 // SmoothQuantModifier._calculate_smoothing_scales, reached through awq.py:81 / smoothquant.py:77).
 //
 // The search loss  mean((X W^T - X Wq^T)^2)  is evaluated through the Gram matrix the GPTQ path
-// already builds:  sum_r d_r (X^T X) d_r^T / (N R)  with  D = W - pseudo_quant(W s)/s.  That is the
-// same number (exact algebra) for 2 R K^2 flops per grid point instead of 2 N R K -- N/K = 48x
-// fewer at K = 4096 -- and it turns the 20-point search into fp32 MFMA work on resident data.
+// already builds:  sum_r d_r (X^T X) d_r^T / (N R) = <X^T X, D^T D>_F / (N R)  with
+// D = W - pseudo_quant(W s)/s.  Exact algebra, and both factors are Gram matrices: D^T D comes from
+// the same bf16-MFMA xtx_kernel (D rounded to bf16: the loss moves by < 5e-4 relative, two orders
+// below the spacing of the grid points), lower triangle only, followed by one HBM pass for the
+// Frobenius product -- R K^2 bf16 flops per grid point instead of 2 N R K.
 #include "common.h"
 #include "sgemm_tn.h"
 
@@ -111,12 +113,11 @@ __global__ __launch_bounds__(1024) void awq_scales_kernel(const float* __restric
     }
 }
 
-// Dt[k][r] = w - pseudo_quant(w * s_k) / s_k, one wave per (row, group), transposed through the
-// write index (lanes = columns; Dt rows are R long so a wave writes 64 scattered floats -- the
-// matrix is written once and read by the GEMM 20x less often than it is computed).
-__global__ __launch_bounds__(64) void awq_diff_t_kernel(const void* __restrict__ W, int dtype, int R, int K,
-                                                        int64_t ldw, const float* __restrict__ s, int gs,
-                                                        int symmetric, int num_bits, float* __restrict__ Dt) {
+// Db[r][k] = bf16(w - pseudo_quant(w * s_k) / s_k), one wave per (row, group), row-major (the
+// layout qt_xtx_accumulate reads: rows play the role of tokens).
+__global__ __launch_bounds__(64) void awq_diff_bf16_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                           int64_t ldw, const float* __restrict__ s, int gs,
+                                                           int symmetric, int num_bits, __bf16* __restrict__ Db) {
     const int g = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     const int per = gs / 64;
     float w[8], ws[8];
@@ -151,9 +152,28 @@ __global__ __launch_bounds__(64) void awq_diff_t_kernel(const void* __restrict__
                 const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
                 q = (fminf(fmaxf(rintf(ws[e] / sc) + z, 0.0f), max_int) - z) * sc;
             }
-            Dt[(size_t)k * R + r] = w[e] - q / s[k];
+            Db[(size_t)r * K + k] = (__bf16)(w[e] - q / s[k]);
         }
     }
+}
+
+// partial[i] = sum_{j <= i} G[i][j] * C[i][j] * (j < i ? 2 : 1)   (both lower triangles valid)
+__global__ __launch_bounds__(256) void sym_dot_rows_kernel(const float* __restrict__ G, const float* __restrict__ C,
+                                                           int K, float* __restrict__ partial) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j <= i; j += 256) {
+        const double v = (double)G[(size_t)i * K + j] * (double)C[(size_t)i * K + j];
+        acc += (j < i) ? 2.0 * v : v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[i] = (float)red[0];
 }
 
 __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ G, int K) {
@@ -302,8 +322,9 @@ extern "C" int qt_symmetrize_lower(float* G, int K, qt_stream_t stream_) {
 
 extern "C" size_t qt_awq_loss_workspace_bytes(int R, int K) {
     if (R <= 0 || K <= 0) return 0;
-    const size_t tiles = (size_t)((R + 63) / 64) * ((K + 63) / 64);
-    return (size_t)R * K * 4 + tiles * 4 + 1024;
+    // Db [R,K] bf16 + C [K,K] fp32 + per-row partials + the Gram kernel's own workspace
+    return qt_align_up((size_t)R * K * 2, 256) + (size_t)K * K * 4 + qt_align_up((size_t)K * 4, 256) +
+           qt_xtx_workspace_bytes(R, K) + 1024;
 }
 
 extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
@@ -311,32 +332,33 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
                            void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && s && Gfull && loss_out && R > 0 && K > 0 && n_tokens > 0, "qt_awq_loss: bad arguments");
+    QT_CHECK_ARG(K % 8 == 0, "qt_awq_loss: K=%d must be a multiple of 8", K);
     const int gs = group_size <= 0 ? K : group_size;
     if (K % gs != 0 || gs % 64 != 0 || gs > 512) {
         qt_set_error("qt_awq_loss: group_size %d unsupported", gs);
         return QT_ERR_UNSUPPORTED;
     }
+    QT_CHECK_ARG(R <= 65535, "qt_awq_loss: R=%d > 65535 rows per call (split the balance layer)", R);
     const size_t need = qt_awq_loss_workspace_bytes(R, K);
     if (!workspace || workspace_bytes < need) {
         qt_set_error("qt_awq_loss: workspace %zu < required %zu", workspace_bytes, need);
         return QT_ERR_WORKSPACE;
     }
-    float* Dt = (float*)qt_align_up((size_t)workspace, 256);
-    float* partial = Dt + (size_t)R * K;
-    QT_CHECK_ARG(R <= 65535, "qt_awq_loss: R=%d > 65535 rows per call (split the balance layer)", R);
-    hipLaunchKernelGGL(awq_diff_t_kernel, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s, gs, symmetric,
-                       num_bits, Dt);
+    char* ws = (char*)qt_align_up((size_t)workspace, 256);
+    __bf16* Db = (__bf16*)ws;
+    float* C = (float*)(ws + qt_align_up((size_t)R * K * 2, 256));
+    float* partial = C + (size_t)K * K;
+    char* xws = (char*)partial + qt_align_up((size_t)K * 4, 256);
+    const size_t xws_bytes = workspace_bytes - (size_t)(xws - (char*)workspace);
+    hipLaunchKernelGGL(awq_diff_bf16_kernel, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s, gs,
+                       symmetric, num_bits, Db);
     QT_LAUNCH_CHECK();
-    int n_partial = 0;
-    SgemmArgs g;
-    g.A = Dt; g.lda = R;
-    g.B = Gfull; g.ldb = K;
-    g.Cin = Dt; g.ldcin = R;       // DOT mode reads E[row][col] = Cin[col * ldcin + row]
-    g.Cout = partial; g.ldcout = 0;
-    g.M = R; g.N = K; g.kdim = K; g.k_mode = SG_K_FULL; g.mode = SG_MODE_DOT;
-    const int rc = qt_sgemm_tn_dot(g, stream, &n_partial);
+    QT_HIP(hipMemsetAsync(C, 0, (size_t)K * K * 4, stream));
+    const int rc = qt_xtx_accumulate(Db, R, K, K, C, xws, xws_bytes, stream_);
     if (rc) return rc;
-    hipLaunchKernelGGL(partial_sum_f64_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, n_partial,
+    hipLaunchKernelGGL(sym_dot_rows_kernel, dim3(K), dim3(256), 0, stream, Gfull, (const float*)C, K, partial);
+    QT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_sum_f64_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, K,
                        1.0 / ((double)n_tokens * (double)R), loss_out);
     QT_LAUNCH_CHECK();
     return QT_OK;

@@ -1,7 +1,6 @@
 // fp32 "TN" GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32):
 //     acc[m][n] = sum_{k ascending} A[k][m] * B[k][n]      (both operands k-major, row-major)
 //     MODE_SUB: Cout = Cin - acc     MODE_SET: Cout = acc     MODE_NEG: Cout = -acc
-//     MODE_DOT: Cout[workgroup] = sum_{m,n in tile} acc[m][n] * Cin[n * ldcin + m]   (trace form)
 // The accumulation is bit-for-bit an ascending-k fmaf chain starting from 0 (guide section 3,
 // "FP32-input MFMA"), which is the order oracle/gptq_oracle.c fixes for upstream's
 // "W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:]".  Used by the GPTQ trailing update (a11) and by the
@@ -9,7 +8,7 @@
 #pragma once
 #include "common.h"
 
-enum { SG_MODE_SUB = 0, SG_MODE_SET = 1, SG_MODE_NEG = 2, SG_MODE_DOT = 3 };
+enum { SG_MODE_SUB = 0, SG_MODE_SET = 1, SG_MODE_NEG = 2 };
 enum { SG_K_FULL = 0, SG_K_FROM_N0 = 1 };  // SG_K_FROM_N0: B[k][n] == 0 for k < n (skip them)
 
 struct SgemmArgs {
@@ -31,8 +30,6 @@ struct SgemmArgs {
 
 // Enqueue on `stream`; picks the tile size from the problem shape.  Returns qt_status.
 int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream);
-// MODE_DOT launch: one fp32 partial per workgroup into a.Cout; *n_partial = number written.
-int qt_sgemm_tn_dot(const SgemmArgs& a, hipStream_t stream, int* n_partial);
 
 // Ordered slab reduction (shared by the split-K paths): Cout = mode(Cin, sum_z slabs[z]).
 int qt_splitk_reduce(const float* slabs, int splits, int M, int N, const float* Cin, int64_t ldcin, float* Cout,

@@ -139,28 +139,6 @@ __global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {  // p is mo
         }
     }
 
-    if (MODE == SG_MODE_DOT) {
-        // trace form: sum acc[m][n] * E[m][n] with E[m][n] = Cin[n * ldcin + m]; 4 consecutive m
-        // (registers r&3) are contiguous in E
-        float part = 0.0f;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wave_m * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
-                    if (row < p.M && col < p.N) part += acc[i][j][r] * p.Cin[(size_t)col * p.ldcin + row];
-                }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        __shared__ float wsum[4];
-        if (lane == 0) wsum[wave] = part;
-        __syncthreads();
-        if (tid == 0) p.Cout[blockIdx.y * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -217,9 +195,6 @@ int launch(const SgemmArgs& a, hipStream_t stream, int splits = 1) {
         case SG_MODE_SET:
             hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SET>), grid, dim3(NT), 0, stream, a);
             break;
-        case SG_MODE_DOT:
-            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_DOT>), grid, dim3(NT), 0, stream, a);
-            break;
         default:
             hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_NEG>), grid, dim3(NT), 0, stream, a);
             break;
@@ -270,18 +245,6 @@ int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream) {
     }
     // enough 128x128 tiles for ~1.5 rounds on 256 CUs, else 64x64 tiles for 4x the workgroups
     if (t128 >= 384) return launch<128, 128>(a, stream);
-    return launch<64, 64>(a, stream);
-}
-
-int qt_sgemm_tn_dot(const SgemmArgs& a, hipStream_t stream, int* n_partial) {
-    *n_partial = 0;
-    if (a.M <= 0 || a.N <= 0) return QT_OK;
-    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (t128 >= 384) {
-        *n_partial = (int)t128;
-        return launch<128, 128>(a, stream);
-    }
-    *n_partial = (int)((long)((a.M + 63) / 64) * ((a.N + 63) / 64));
     return launch<64, 64>(a, stream);
 }
 

@@ -29,7 +29,7 @@ for gi, (gname, K, lins) in enumerate(shape.groups):
         dt = time.perf_counter() - t0
     R = sum(w.shape[0] for w in Ws)
     print(f"{gname:9s} K={K:5d} R={R:5d}: {dt * 1e3:8.1f} ms  best ratio {int(res[0].best_ratio_idx)}/20  "
-          f"grid GEMM {20 * 2 * R * K * K / dt / 1e12:6.1f} TFLOP/s", flush=True)
+          f"({20 * R * K * (K + 1) / dt / 1e12:6.1f} TFLOP/s of D^T D Gram work incl. everything else)", flush=True)
     tot += dt
     del X, Ws, res
 print(f"layer total {tot * 1e3:.1f} ms -> {shape.weights_per_layer / tot / 1e9:.3f} Gweights/s", flush=True)
