@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from quantool_amd.engine.sharding import gather_state_dict, group_cost, lpt_assign, my_units
+from quantool_amd.engine.sharding import allreduce_gram, gather_state_dict, group_cost, lpt_assign, my_units
 
 
 def test_lpt_assignment_is_balanced_and_deterministic():
@@ -45,6 +45,12 @@ def _worker(rank, world, port, q):
             local[f"{units[i]}.weight_packed"] = torch.randint(-2 ** 31, 2 ** 31 - 1, (8, 4), generator=g,
                                                                dtype=torch.int32)
             local[f"{units[i]}.weight_scale"] = torch.randn(8, 2, generator=g).to(torch.bfloat16)
+        # partitioning B: token-split Gram partials summed across ranks
+        g = torch.Generator().manual_seed(7)
+        X = torch.randn(64, 16, generator=g, dtype=torch.float64)
+        part = X[rank::world].t() @ X[rank::world]
+        n_tot = allreduce_gram(part, 32 // world + (1 if rank == 0 else 0))
+        assert n_tot == 33 and torch.allclose(part, X.t() @ X)
         merged = gather_state_dict(local, dst=0)
         if rank == 0:
             ok = len(merged) == 10
