@@ -81,7 +81,10 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0)
     main = torch.cuda.current_stream(dev)
     for gi, (gname, K, lins) in enumerate(groups):
         if overlap:
-            st = _STREAMS.setdefault((dev.index, lane, gi), torch.cuda.Stream(device=dev))
+            # stream slots per layer: "all4" = one per group; "two" = the largest-K group alone, the rest
+            # share one stream (diagnostic knob; default all4)
+            slot = gi if os.environ.get("QT_BENCH_GROUPING", "all4") == "all4" else min(gi, 1)
+            st = _STREAMS.setdefault((dev.index, lane, slot), torch.cuda.Stream(device=dev))
             st.wait_stream(main)
         else:
             st = main
