@@ -22,8 +22,7 @@ constexpr int BT = 256;                    // output tile edge (channels)
 constexpr int BKT = 64;                    // tokens per K-step
 constexpr int NTHREADS = 512;              // 8 waves: 2 (M) x 4 (N), 128x64 outputs per wave
 constexpr int OP_BYTES = BKT * BT * 2;     // one operand panel in LDS (32 KiB)
-constexpr int STAGE_BYTES = 2 * OP_BYTES;  // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES; // double buffered (128 KiB)
+constexpr int STAGE_BYTES = 2 * OP_BYTES;  // A + B; two stages = 128 KiB of LDS
 constexpr int NUM_CU = 256;
 
 struct XtxParams {
