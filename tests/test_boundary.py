@@ -10,7 +10,7 @@ import yaml
 import quantool_amd.methods  # noqa: F401  (registers the plugins)
 from quantool_amd.core import BaseQuantizer, QuantizerRegistry, Registry, TemplateQuantizationCard
 from quantool_amd.engine.modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
-from quantool_amd.methods.hip_compressor.base import HipCompressorQuantizer
+from quantool_amd.methods.hip_compressor import HipCompressorQuantizer
 
 GOLD = Path(__file__).resolve().parent / "golden"
 
@@ -84,7 +84,7 @@ def test_gptq_recipe_defaults_and_passthrough():
     assert not recipe.weight_args().symmetric
 
 
-def test_invalid_scheme_is_a_value_error_with_the_reference_wording():
+def test_invalid_scheme_is_a_value_error():
     for name in ("gptq", "awq", "smoothquant"):
         q = QuantizerRegistry.create(name, model_id="m")
         with pytest.raises(ValueError, match="is not a valid compressed-tensors preset scheme"):
