@@ -147,6 +147,11 @@ size_t qt_awq_loss_workspace_bytes(int R, int K);
 int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
                 int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, float* loss_out,
                 void* workspace, size_t workspace_bytes, qt_stream_t stream);
+/* out[R,K] (W's dtype, leading dimension ldo) = pseudo_quant(W * s) / s: the trial weights of one
+ * grid point, for mappings whose search loss is measured on a parent module's output (q/k/v under
+ * self_attn, gate/up under mlp) rather than on the balance Linear's own.  out may alias W. */
+int qt_awq_pseudo_quantize(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
+                           int symmetric, int num_bits, void* out, int64_t ldo, qt_stream_t stream);
 /* out = W * s[None, :] (divide != 0: W / s), rounded to W's dtype (AWQ / SmoothQuant apply step). */
 int qt_scale_columns(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int divide,
                      void* out, int64_t ldo, qt_stream_t stream);

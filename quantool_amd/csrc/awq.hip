@@ -113,11 +113,15 @@ __global__ __launch_bounds__(1024) void awq_scales_kernel(const float* __restric
     }
 }
 
-// Db[r][k] = bf16(w - pseudo_quant(w * s_k) / s_k), one wave per (row, group), row-major (the
-// layout qt_xtx_accumulate reads: rows play the role of tokens).
-__global__ __launch_bounds__(64) void awq_diff_bf16_kernel(const void* __restrict__ W, int dtype, int R, int K,
-                                                           int64_t ldw, const float* __restrict__ s, int gs,
-                                                           int symmetric, int num_bits, __bf16* __restrict__ Db) {
+// One wave per (row, group).  DIFF: Db[r][k] = bf16(w - pseudo_quant(w * s_k) / s_k), row-major
+// with leading dimension K (the layout qt_xtx_accumulate reads: rows play the role of tokens).
+// !DIFF: out[r][k] = pseudo_quant(w * s_k) / s_k in the weight's own dtype, leading dimension ldo
+// (the trial weights of one grid point when the search loss needs a forward of the parent module).
+template <bool DIFF>
+__global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                              int64_t ldw, const float* __restrict__ s, int gs,
+                                                              int symmetric, int num_bits, void* __restrict__ out,
+                                                              int64_t ldo) {
     const int g = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     const int per = gs / 64;
     float w[8], ws[8];
@@ -152,7 +156,13 @@ __global__ __launch_bounds__(64) void awq_diff_bf16_kernel(const void* __restric
                 const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
                 q = (fminf(fmaxf(rintf(ws[e] / sc) + z, 0.0f), max_int) - z) * sc;
             }
-            Db[(size_t)r * K + k] = (__bf16)(w[e] - q / s[k]);
+            if (DIFF) {
+                ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(w[e] - q / s[k]);
+            } else if (dtype == QT_F32) {
+                ((float*)out)[(size_t)r * ldo + k] = q / s[k];
+            } else {
+                ((__bf16*)out)[(size_t)r * ldo + k] = (__bf16)(q / s[k]);
+            }
         }
     }
 }
@@ -350,8 +360,8 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
     float* partial = C + (size_t)K * K;
     char* xws = (char*)partial + qt_align_up((size_t)K * 4, 256);
     const size_t xws_bytes = workspace_bytes - (size_t)(xws - (char*)workspace);
-    hipLaunchKernelGGL(awq_diff_bf16_kernel, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s, gs,
-                       symmetric, num_bits, Db);
+    hipLaunchKernelGGL(awq_pseudo_quant_kernel<true>, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s,
+                       gs, symmetric, num_bits, (void*)Db, (int64_t)K);
     QT_LAUNCH_CHECK();
     QT_HIP(hipMemsetAsync(C, 0, (size_t)K * K * 4, stream));
     const int rc = qt_xtx_accumulate(Db, R, K, K, C, xws, xws_bytes, stream_);
@@ -361,6 +371,29 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
     hipLaunchKernelGGL(partial_sum_f64_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, K,
                        1.0 / ((double)n_tokens * (double)R), loss_out);
     QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_awq_pseudo_quantize(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s,
+                                       int group_size, int symmetric, int num_bits, void* out, int64_t ldo,
+                                       qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && s && out && R > 0 && K > 0, "qt_awq_pseudo_quantize: bad arguments");
+    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_awq_pseudo_quantize: dtype %d unsupported", w_dtype);
+    QT_CHECK_ARG(num_bits >= 2 && num_bits <= 8, "qt_awq_pseudo_quantize: num_bits=%d", num_bits);
+    const int gs = group_size <= 0 ? K : group_size;
+    if (K % gs != 0 || gs % 64 != 0 || gs > 512) {
+        qt_set_error("qt_awq_pseudo_quantize: group_size %d unsupported", gs);
+        return QT_ERR_UNSUPPORTED;
+    }
+    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    for (int row0 = 0; row0 < R; row0 += 32768) {   // gridDim.y limit
+        const int rows = (R - row0 < 32768) ? R - row0 : 32768;
+        hipLaunchKernelGGL(awq_pseudo_quant_kernel<false>, dim3(K / gs, rows), dim3(64), 0, stream,
+                           (const void*)((const char*)W + (size_t)row0 * ldw * esz), w_dtype, rows, K, ldw, s, gs,
+                           symmetric, num_bits, (void*)((char*)out + (size_t)row0 * ldo * esz), ldo);
+        QT_LAUNCH_CHECK();
+    }
     return QT_OK;
 }
 

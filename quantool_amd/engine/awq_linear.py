@@ -31,6 +31,12 @@ class AWQResult:
     scaled_weight: torch.Tensor = field(repr=False, default=None)   # W * s in model dtype
     scale_f32: torch.Tensor = field(repr=False, default=None)
     zp_f32: torch.Tensor = field(repr=False, default=None)
+    Qt: torch.Tensor = field(repr=False, default=None)              # int8 [K, R] levels
+    g_of_col: torch.Tensor = field(repr=False, default=None)        # int32 [K]
+
+    def dequantized(self, dtype=torch.float32) -> torch.Tensor:
+        """(q - zp) * scale: the weight upstream leaves in the module after the observer pass."""
+        return ops.dequantize(self.Qt, self.scale_f32, self.zp_f32, self.g_of_col, None, dtype)
 
 
 def awq_search(weights: Sequence[torch.Tensor], batches: Iterable[torch.Tensor], qargs: QuantArgs, *,
@@ -67,23 +73,27 @@ def awq_search(weights: Sequence[torch.Tensor], batches: Iterable[torch.Tensor],
     return scales, losses, best, n_tokens
 
 
+def rtn_finalize(ws: torch.Tensor, qargs: QuantArgs, s: Optional[torch.Tensor] = None,
+                 best: Optional[torch.Tensor] = None, losses: Optional[torch.Tensor] = None) -> AWQResult:
+    """Standard observer (/7.5) + round-to-nearest + pack of an already smoothed weight ``ws``."""
+    R, K = ws.shape
+    gs = qargs.kernel_group_size
+    scale, zp, _, _ = ops.group_minmax_qparams(ws, gs, qargs.symmetric, qargs.num_bits)
+    Qt = ops.rtn_quantize(ws, scale, zp, gs, qargs.num_bits)
+    packed = ops.pack_int4(Qt) if qargs.num_bits == 4 else None
+    sdt = ws.dtype if ws.dtype in (torch.bfloat16, torch.float16) else torch.float32
+    g_of_col = (torch.arange(K, dtype=torch.int32, device=ws.device) // (K if gs <= 0 else gs)).contiguous()
+    return AWQResult(
+        weight_packed=packed, weight_q=None if packed is not None else Qt.t().contiguous(),
+        weight_scale=scale.to(sdt), weight_zero_point=None if qargs.symmetric else zp.to(torch.int8),
+        weight_g_idx=None, weight_shape=torch.tensor([R, K], dtype=torch.int64), smoothing_scales=s,
+        best_ratio_idx=best, losses=losses, scaled_weight=ws, scale_f32=scale, zp_f32=zp, Qt=Qt, g_of_col=g_of_col)
+
+
 def awq_quantize_group(weights: Sequence[torch.Tensor], batches: Iterable[torch.Tensor], qargs: QuantArgs, *,
                        n_grid: int = 20, duo_scaling: bool = True, device=None) -> List[AWQResult]:
     scales, losses, best, _ = awq_search(weights, batches, qargs, n_grid=n_grid, duo_scaling=duo_scaling,
                                          device=device)
     s = scales[best].contiguous()
-    gs = qargs.kernel_group_size
-    out: List[AWQResult] = []
-    for w in weights:
-        R, K = w.shape
-        ws = ops.scale_columns(w, s)                                        # W_balance *= s (model dtype)
-        scale, zp, _, _ = ops.group_minmax_qparams(ws, gs, qargs.symmetric, qargs.num_bits)
-        Qt = ops.rtn_quantize(ws, scale, zp, gs, qargs.num_bits)
-        packed = ops.pack_int4(Qt) if qargs.num_bits == 4 else None
-        sdt = w.dtype if w.dtype in (torch.bfloat16, torch.float16) else torch.float32
-        out.append(AWQResult(
-            weight_packed=packed, weight_q=None if packed is not None else Qt.t().contiguous(),
-            weight_scale=scale.to(sdt), weight_zero_point=None if qargs.symmetric else zp.to(torch.int8),
-            weight_g_idx=None, weight_shape=torch.tensor([R, K], dtype=torch.int64), smoothing_scales=s,
-            best_ratio_idx=best, losses=losses, scaled_weight=ws, scale_f32=scale, zp_f32=zp))
-    return out
+    # W_balance *= s (model dtype), then the plain observer path
+    return [rtn_finalize(ops.scale_columns(w, s), qargs, s, best, losses) for w in weights]

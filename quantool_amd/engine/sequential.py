@@ -18,7 +18,7 @@ from typing import Any, Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from .gptq_linear import GPTQResult, HessianAccumulator, gptq_quantize_shared
+from .gptq_linear import HessianAccumulator, gptq_quantize_shared
 from .modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
 
 logger = logging.getLogger(__name__)
@@ -112,11 +112,12 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
     mods = recipe if isinstance(recipe, (list, tuple)) else [recipe]
     gp = next((m for m in mods if isinstance(m, GPTQModifier)), None)
     sq = next((m for m in mods if isinstance(m, SmoothQuantModifier)), None)
-    if any(isinstance(m, AWQModifier) for m in mods):
-        raise NotImplementedError("AWQ on nn.Module models needs the mapping resolver (next round); "
-                                  "use LinearCalibrationSet groups (engine.oneshot) for AWQ")
-    if gp is None:
-        raise ValueError("recipe must contain a GPTQModifier")
+    aw = next((m for m in mods if isinstance(m, AWQModifier)), None)
+    if gp is None and aw is None:
+        raise ValueError("recipe must contain a GPTQModifier or an AWQModifier")
+    if gp is not None and aw is not None:
+        raise ValueError("GPTQModifier and AWQModifier in one recipe: pick one weight quantizer")
+    qm = gp if gp is not None else aw
     if isinstance(model, (str, Path)):
         from transformers import AutoModelForCausalLM, AutoTokenizer
 
@@ -141,7 +142,7 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
     model.eval()
     model.to(dev)
     layers = find_decoder_layers(model)
-    qargs = gp.weight_args()
+    qargs = qm.weight_args()
 
     # ---- inputs of the first decoder layer -------------------------------------------------------
     cache: List[tuple] = []
@@ -160,10 +161,16 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
     h.remove()
 
     prefix_of = {id(m): n for n, m in model.named_modules()}
-    results: Dict[str, GPTQResult] = {}
+    results: Dict[str, Any] = {}
     with torch.no_grad():
         for li, layer in enumerate(layers):
             lname = prefix_of[id(layer)]
+            if aw is not None:
+                from .awq_module import awq_layer
+
+                results.update(awq_layer(layer, lname, cache, aw, dev))
+                cache = _advance(layer, cache)
+                continue
             linears = {f"{lname}.{n}" if n else lname: m for n, m in layer.named_modules()
                        if isinstance(m, nn.Linear) and gp.wants(f"{lname}.{n}", m)}
             if sq is not None:
@@ -202,18 +209,22 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                     linears[n].weight.data.copy_(r.dequantized(linears[n].weight.dtype))
                     results[n] = r
                 del accs[lead]
-            # next layer's inputs, with the quantised weights
-            new_cache = []
-            for args, kwargs in cache:
-                out = layer(*args, **kwargs)
-                out = out[0] if isinstance(out, (tuple, list)) else out
-                new_cache.append(((out,) + tuple(args[1:]), kwargs))
-            cache = new_cache
+            cache = _advance(layer, cache)
             logger.info(f"quantized {lname}: {len(linears)} Linears in {len(leaders)} input groups")
     model._qt_results = results
-    model._qt_meta = {"weights": qargs.to_config(), "format": gp.resolved_scheme.format, "ignore": list(gp.ignore)}
+    model._qt_meta = {"weights": qargs.to_config(), "format": qm.resolved_scheme.format, "ignore": list(qm.ignore)}
     model.save_pretrained = types.MethodType(_save_compressed, model)
     return model
+
+
+def _advance(layer: nn.Module, cache):
+    """Next layer's inputs: this layer re-run on its cached inputs with the quantised weights."""
+    new_cache = []
+    for args, kwargs in cache:
+        out = layer(*args, **kwargs)
+        out = out[0] if isinstance(out, (tuple, list)) else out
+        new_cache.append(((out,) + tuple(args[1:]), kwargs))
+    return new_cache
 
 
 def _smooth_layer(layer: nn.Module, cache, alpha: float, dev) -> None:

@@ -323,6 +323,22 @@ def awq_loss(W: torch.Tensor, s: torch.Tensor, group_size: int, symmetric: bool,
                                          out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
 
 
+def awq_pseudo_quantize(W: torch.Tensor, s: torch.Tensor, group_size: int, symmetric: bool, num_bits: int,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pseudo_quant(W * s) / s in W's dtype (one grid point's trial weights)."""
+    lib = load()
+    R, K = _w2d(W)
+    _req(s, torch.float32, "s", 1)
+    assert s.numel() == K and s.is_contiguous()
+    if out is None:
+        out = torch.empty((R, K), dtype=W.dtype, device=W.device)
+    assert out.shape == (R, K) and out.dtype == W.dtype and out.stride(1) == 1 and out.device == W.device
+    check("qt_awq_pseudo_quantize",
+          lib.qt_awq_pseudo_quantize(W.data_ptr(), _dtype_code(W), R, K, W.stride(0), s.data_ptr(), group_size,
+                                     int(bool(symmetric)), num_bits, out.data_ptr(), out.stride(0), _stream()))
+    return out
+
+
 def scale_columns(W: torch.Tensor, s: torch.Tensor, divide: bool = False) -> torch.Tensor:
     lib = load()
     R, K = _w2d(W)
