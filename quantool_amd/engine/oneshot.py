@@ -71,7 +71,11 @@ class QuantizedLinears:
     def quantization_config(self) -> dict:
         from .serialization import quantization_config
 
-        return quantization_config(self.weight_config, self.format, self.ignore)
+        from .schemes import preset_name_to_scheme
+
+        acts = preset_name_to_scheme(self.scheme_name).input_activations
+        return quantization_config(self.weight_config, self.format, self.ignore,
+                                   acts.to_config() if acts is not None else None)
 
     def save_pretrained(self, save_directory, save_compressed: bool = True, **_):
         from .serialization import save_state

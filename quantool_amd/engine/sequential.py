@@ -103,7 +103,7 @@ def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = T
                 state[f"{mod}.{k}"] = v
     base_cfg = model.config.to_dict() if hasattr(model, "config") and hasattr(model.config, "to_dict") else {}
     save_state(state, quantization_config(meta.get("weights", {}), meta.get("format", "pack-quantized"),
-                                          meta.get("ignore", [])), save_directory, base_cfg)
+                                          meta.get("ignore", []), meta.get("input_activations")), save_directory, base_cfg)
 
 
 def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int, max_seq_length: int, shuffle: bool,
@@ -212,7 +212,9 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             cache = _advance(layer, cache)
             logger.info(f"quantized {lname}: {len(linears)} Linears in {len(leaders)} input groups")
     model._qt_results = results
-    model._qt_meta = {"weights": qargs.to_config(), "format": qm.resolved_scheme.format, "ignore": list(qm.ignore)}
+    acts = qm.resolved_scheme.input_activations
+    model._qt_meta = {"weights": qargs.to_config(), "format": qm.resolved_scheme.format, "ignore": list(qm.ignore),
+                      "input_activations": acts.to_config() if acts is not None else None}
     model.save_pretrained = types.MethodType(_save_compressed, model)
     return model
 

@@ -31,14 +31,17 @@ def result_tensors(r) -> Dict[str, torch.Tensor]:
     return out
 
 
-def quantization_config(weight_config: dict, fmt: str, ignore) -> dict:
+def quantization_config(weight_config: dict, fmt: str, ignore, input_activations: dict = None) -> dict:
+    """``input_activations`` is the scheme's activation block (W8A8 / INT8 / W4A8: 8-bit dynamic
+    per-token): dynamic observers hold no calibration state, so the block is
+    configuration only -- the runtime that loads the checkpoint quantises activations on the fly."""
     return {
         "quant_method": "compressed-tensors",
         "format": fmt,
         "quantization_status": "compressed",
         "global_compression_ratio": None,
         "config_groups": {
-            "group_0": {"targets": ["Linear"], "weights": weight_config, "input_activations": None,
+            "group_0": {"targets": ["Linear"], "weights": weight_config, "input_activations": input_activations,
                         "output_activations": None}
         },
         "ignore": list(ignore),

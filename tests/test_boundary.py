@@ -265,3 +265,21 @@ def test_oneshot_refuses_to_run_without_gpu_or_library():
         pytest.skip("GPU present")
     with pytest.raises((RuntimeError, ImportError)):
         oneshot(model=LinearCalibrationSet(groups=[]), recipe=GPTQModifier(), dataset=[1])
+
+
+@pytest.mark.parametrize("scheme,acts", [("W4A16", None), ("W8A16", None), ("W8A8", (8, "token", True, True)),
+                                         ("INT8", (8, "token", True, True)), ("W4A8", (8, "token", True, False))])
+def test_quantization_config_carries_the_activation_block(scheme, acts):
+    """N4: schemes with 8-bit activations are dynamic per-token -- configuration only, written next to
+    the weight arguments so a compressed-tensors loader sets up the runtime quantiser."""
+    from quantool_amd.engine.oneshot import QuantizedLinears
+
+    mod = GPTQModifier(scheme=scheme)
+    ql = QuantizedLinears({}, mod, mod.scheme, mod.resolved_scheme.format, mod.weight_args().to_config(), ["lm_head"])
+    group = ql.quantization_config()["config_groups"]["group_0"]
+    if acts is None:
+        assert group["input_activations"] is None
+    else:
+        a = group["input_activations"]
+        assert (a["num_bits"], a["strategy"], a["dynamic"], a["symmetric"]) == acts
+    assert ql.quantization_config()["format"] == mod.resolved_scheme.format

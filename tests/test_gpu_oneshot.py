@@ -75,6 +75,7 @@ def test_plugin_quantize_on_linear_calibration_set(dev, oracle, tmp_path, monkey
     assert cfg["format"] == "pack-quantized" and cfg["ignore"] == ["lm_head"]
     w = cfg["config_groups"]["group_0"]["weights"]
     assert (w["num_bits"], w["symmetric"], w["strategy"], w["group_size"]) == (4, True, "group", 128)
+    assert cfg["config_groups"]["group_0"]["input_activations"] is None        # W4A16: weight-only
     # parity of the stacked sweep: q_proj rows equal a stand-alone run's rows (rows are independent)
     from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_linear
     from quantool_amd.engine.schemes import QuantArgs

@@ -107,3 +107,8 @@ def test_smoothquant_plus_gptq_on_tiny_llama(dev, tmp_path, monkeypatch):
     # int8 channel-wise + smoothing keeps the function close
     rel = (after - before).norm() / before.norm()
     assert rel < 0.1, rel
+    q.save_pretrained(str(tmp_path / "w8a8"))
+    group = json.loads((tmp_path / "w8a8" / "config.json").read_text())["quantization_config"]["config_groups"]["group_0"]
+    a = group["input_activations"]
+    assert (a["num_bits"], a["strategy"], a["dynamic"], a["symmetric"]) == (8, "token", True, True)
+    assert group["weights"]["strategy"] == "channel" and group["weights"]["num_bits"] == 8
