@@ -36,6 +36,7 @@ import torch  # noqa: E402
 N_SAMPLES = 512
 SEQ_LEN = 384
 MODEL = "llama-3-8b"
+REHEARSE = os.environ.get("QT_BENCH_REHEARSE_GLOO") == "1"   # see main(): N>1 control flow on a one-GPU box
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
@@ -203,8 +204,14 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if REHEARSE:
+            # one-GPU rehearsal of the N>1 control flow: every rank on cuda:0, gloo for the host side
+            # (RCCL refuses two ranks on one device).  Numbers from this mode are not benchmark results.
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            local_rank = 0
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
@@ -247,7 +254,7 @@ def main():
         from quantool_amd.engine.sharding import gather_state_dict
 
         local = {f"layers.{rank + world * i}.{k}": v for i, outs in enumerate(kept) for k, v in outs.items()}
-        merged = gather_state_dict(local, dst=0, device=dev)
+        merged = gather_state_dict(local, dst=0, device=None if REHEARSE else dev)
         if rank == 0:
             assert len(merged) == len(local) * world
     barrier()
@@ -277,7 +284,7 @@ def main():
         lib.qt_profile_enable(0)
         iso_ms = t_iso.value
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if REHEARSE else dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
@@ -314,7 +321,7 @@ def main():
             "metric": "quantized weights/sec (GPTQ int4, Llama-3-8B, 512 calib samples)",
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {
                 "workload": ("Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder=static, "
                              "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "

@@ -68,21 +68,21 @@ def gather_state_dict(local: Dict[str, torch.Tensor], dst: int = 0, group=None, 
         flat = flat.to(device)
     metas = [None] * world
     dist.all_gather_object(metas, (meta, int(flat.numel())), group=group)
+    # Posted as ONE batch so that RCCL runs the transfers as a group: the receives on ``dst`` then
+    # progress concurrently, one per xGMI link, instead of one after the other.
     if rank == dst:
         merged = dict(_unflatten(flat, meta))
-        bufs, reqs = {}, []
-        for r in range(world):
-            if r == dst or metas[r][1] == 0:
-                continue
-            bufs[r] = torch.empty(metas[r][1], dtype=torch.uint8, device=flat.device)
-            reqs.append(dist.irecv(bufs[r], src=r, group=group))
-        for q in reqs:
-            q.wait()
+        bufs = {r: torch.empty(metas[r][1], dtype=torch.uint8, device=flat.device)
+                for r in range(world) if r != dst and metas[r][1] > 0}
+        if bufs:
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, r, group) for r, buf in bufs.items()]):
+                q.wait()
         for r, buf in bufs.items():
             merged.update(_unflatten(buf, metas[r][0]))
         return merged
     if flat.numel():
-        dist.send(flat, dst=dst, group=group)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, dst, group)]):
+            q.wait()
     return None
 
 
