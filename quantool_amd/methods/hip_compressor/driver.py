@@ -89,7 +89,7 @@ class HipCompressorQuantizer(BaseQuantizer):
         return True
 
     def prepare_calibration_data(self, dataset, tokenizer=None):
-        """Chat-template rows through quantool's textifier when it is importable, then guarantee a
+        """Chat-template conversational rows (``utils/calibration_text.py``), then guarantee a
         ``text`` column, falling back to prompt/completion/chosen/rejected/label (reference
         ``base.py:271-315``).  Every failure is a warning: calibration data is passed on as is."""
         if tokenizer is not None:
@@ -107,8 +107,9 @@ class HipCompressorQuantizer(BaseQuantizer):
 
     def _apply_chat_template(self, dataset, tokenizer):
         try:
-            from quantool.utils.dataset_textifier import convert_row  # quantool's front-end
+            from ...utils.calibration_text import row_converter
 
+            convert_row = row_converter()
             dataset = dataset.map(lambda row: convert_row(row, tokenizer), batched=False)
             self.logger.info("calibration rows rendered through the chat template")
         except Exception as exc:  # noqa: BLE001
