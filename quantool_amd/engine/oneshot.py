@@ -22,6 +22,7 @@ from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import torch
 
+from ..hip import ops
 from .gptq_linear import GPTQResult, HessianAccumulator, gptq_quantize_shared
 from .modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
 
@@ -36,6 +37,10 @@ class LinearGroup:
     activations: Any
     weights: Dict[str, torch.Tensor]
     num_samples: Optional[int] = None
+    #: 1-d parameters of the op that PRODUCES ``activations`` (a norm's weight / bias), by name.  Given,
+    #: the group is a SmoothQuant mapping: a recipe with a SmoothQuantModifier rescales weights, these
+    #: vectors and the activations; absent, the group is left alone by the smoothing stage.
+    smooth_vectors: Optional[Dict[str, torch.Tensor]] = None
 
 
 @dataclass
@@ -51,8 +56,11 @@ class QuantizedLinears:
     """Result of ``oneshot`` on a ``LinearCalibrationSet``: the compressed state_dict."""
 
     def __init__(self, results: Dict[str, Any], recipe, scheme_name: str, fmt: str, weight_config: dict,
-                 ignore: List[str]):
+                 ignore: List[str], smoothed: Optional[Dict[str, torch.Tensor]] = None,
+                 smoothing_scales: Optional[Dict[str, torch.Tensor]] = None):
         self.results = results
+        self.smoothed = smoothed or {}                    # norm weights / biases after the SmoothQuant stage
+        self.smoothing_scales = smoothing_scales or {}    # group name -> s[K]
         self.recipe = recipe
         self.scheme_name = scheme_name
         self.format = fmt
@@ -66,6 +74,7 @@ class QuantizedLinears:
         for name, r in self.results.items():
             for k, v in result_tensors(r).items():
                 sd[f"{name}.{k}"] = v
+        sd.update(self.smoothed)
         return sd
 
     def quantization_config(self) -> dict:
@@ -104,19 +113,31 @@ def _select_modifiers(recipe) -> Tuple[Optional[SmoothQuantModifier], Optional[G
 def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLinears:
     sq, gp, aw = _select_modifiers(recipe)
     results: Dict[str, Any] = {}
+    smoothed: Dict[str, torch.Tensor] = {}
+    smoothing_scales: Dict[str, torch.Tensor] = {}
     if gp is not None:
         qargs = gp.weight_args()
         for g in cal.groups:
-            names = [n for n in g.weights if n.split(".")[-1] not in gp.ignore and n not in gp.ignore]
+            weights = {n: w.to(device) for n, w in g.weights.items()}
+            rescale = None
+            if sq is not None and g.smooth_vectors:
+                # SmoothQuant stage of the recipe: every Linear of the group is a balance
+                # layer -- ignored ones included, they read the same rescaled activation
+                rescale = _smooth_group(g, weights, sq.smoothing_strength, device, smoothed)
+                smoothing_scales[g.name] = rescale
+            names = [n for n in weights if n.split(".")[-1] not in gp.ignore and n not in gp.ignore]
             if not names:
                 continue
-            K = g.weights[names[0]].shape[1]
+            K = weights[names[0]].shape[1]
             acc = HessianAccumulator(K, device)
             for xb in _iter_batches(g.activations):
-                acc.add(xb.to(device), num_samples=None)
+                xb = xb.to(device)
+                if rescale is not None:      # what the smoothed norm now emits: X / s, in the activation dtype
+                    xb = ops.scale_columns(xb.reshape(-1, K), rescale, divide=True).reshape(xb.shape)
+                acc.add(xb, num_samples=None)
             if g.num_samples is not None:
                 acc.n = int(g.num_samples)
-            res = gptq_quantize_shared([g.weights[n].to(device) for n in names], acc, qargs,
+            res = gptq_quantize_shared([weights[n] for n in names], acc, qargs,
                                        block_size=gp.block_size, dampening_frac=gp.dampening_frac)
             results.update(dict(zip(names, res)))
         mod = gp
@@ -132,7 +153,27 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
                                      n_grid=aw.n_grid, duo_scaling=aw.duo_scaling, device=device)
             results.update(dict(zip(names, res)))
         mod = aw
-    return QuantizedLinears(results, recipe, mod.scheme, mod.resolved_scheme.format, qargs.to_config(), list(mod.ignore))
+    return QuantizedLinears(results, recipe, mod.scheme, mod.resolved_scheme.format, qargs.to_config(), list(mod.ignore),
+                            smoothed, smoothing_scales)
+
+
+def _smooth_group(g: LinearGroup, weights: Dict[str, torch.Tensor], alpha: float, device,
+                  smoothed: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """s = (max - min of the activation)^alpha / (max |W| over the group's Linears)^(1-alpha);
+    ``weights`` are replaced by W * s in place of the dict, the producing vectors by v / s."""
+    from .smoothquant import ChannelMinMax, apply_smoothing, smoothquant_scales
+
+    names = list(weights)
+    K = weights[names[0]].shape[1]
+    stats = ChannelMinMax(K, device)
+    for xb in _iter_batches(g.activations):
+        stats.add(xb.to(device).reshape(-1, K))
+    s = smoothquant_scales(stats, [weights[n] for n in names], alpha)
+    vec_names = list(g.smooth_vectors)
+    new_w, new_v = apply_smoothing(s, [weights[n] for n in names], [g.smooth_vectors[n].to(device) for n in vec_names])
+    weights.update(zip(names, new_w))
+    smoothed.update(zip(vec_names, new_v))
+    return s
 
 
 def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = None,
