@@ -367,16 +367,18 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     float* Y = U;
     const size_t inv_lds = (size_t)(NB * LDT + NB * LDP) * sizeof(float);
     const size_t potf2_lds = (size_t)(NB * LDA + 4 * 32 * 32) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QT_HIP(hipFuncSetAttribute((const void*)potf2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)potf2_lds));
-        QT_HIP(hipFuncSetAttribute((const void*)trsm_rt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(RD_STRIDE * sizeof(float))));
-        QT_HIP(hipFuncSetAttribute((const void*)trinv_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)inv_lds));
-        attr_set = true;
-    }
+    static QtOncePerDevice lds_attr;
+    QT_HIP(lds_attr.run([&] {
+        hipError_t e = hipFuncSetAttribute((const void*)potf2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)potf2_lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trsm_rt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(RD_STRIDE * sizeof(float)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trinv_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)inv_lds);
+        return e;
+    }));
     QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), stream));
 
     // ---- A = R^T R, left-looking by block rows ----

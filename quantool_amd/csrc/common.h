@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/quantool_amd.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -47,6 +49,26 @@ void qt_prof_mark(int kernel_id, hipStream_t stream);  // no-op unless qt_profil
     } while (0)
 
 static inline size_t qt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Per-device, thread-safe "do once": kernel attributes (dynamic LDS size) belong to a device, and
+// the entry points may be called from several host threads (one per stream).  Usage:
+//   static QtOncePerDevice once;  QT_HIP(once.run([&] { return hipFuncSetAttribute(...); }));
+struct QtOncePerDevice {
+    std::mutex m;
+    uint64_t done = 0;
+    template <class F>
+    hipError_t run(F&& f) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        std::lock_guard<std::mutex> lock(m);
+        if (done & bit) return hipSuccess;
+        e = f();
+        if (e == hipSuccess) done |= bit;
+        return e;
+    }
+};
 
 __device__ __forceinline__ float qt_bf16_to_f32(unsigned short h) {
     return __uint_as_float(((unsigned)h) << 16);

@@ -172,12 +172,11 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
     }
     float* ErrT = (float*)qt_align_up((size_t)workspace, 256);
     const float qmin = -(float)(1 << (num_bits - 1)), qmax = (float)((1 << (num_bits - 1)) - 1);
-    static bool attr_set = false;
-    if (!attr_set) {
-        QT_HIP(hipFuncSetAttribute((const void*)sweep_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)SWEEP_LDS));
-        attr_set = true;
-    }
+    static QtOncePerDevice lds_attr;
+    QT_HIP(lds_attr.run([&] {
+        return hipFuncSetAttribute((const void*)sweep_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)SWEEP_LDS);
+    }));
     QT_HIP(hipMemsetAsync(loss, 0, (size_t)R * 4, stream));
     for (int i1 = 0; i1 < K; i1 += BS) {
         const int i2 = (i1 + BS < K) ? i1 + BS : K;

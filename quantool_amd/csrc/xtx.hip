@@ -299,10 +299,17 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     __bf16* tail = pl.has_tail ? (__bf16*)(ws + pl.slab_bytes) : nullptr;
     int* tile_tab = (int*)(ws + pl.slab_bytes + pl.tail_bytes);
     {
-        // host copy kept alive for the life of the process (the async copy reads it)
+        // host copy kept alive for the life of the process (the async copy reads it); std::map
+        // nodes do not move, so the reference stays valid after the lock is dropped
+        static std::mutex tabs_mutex;
         static std::map<int, std::vector<int>> tabs;
-        std::vector<int>& tab = tabs[K];
-        if (tab.empty()) xtx_tile_order((K + BT - 1) / BT, tab);
+        std::vector<int>* tab_ptr;
+        {
+            std::lock_guard<std::mutex> lock(tabs_mutex);
+            tab_ptr = &tabs[K];
+            if (tab_ptr->empty()) xtx_tile_order((K + BT - 1) / BT, *tab_ptr);
+        }
+        std::vector<int>& tab = *tab_ptr;
         if ((int)tab.size() != pl.n_tiles) {
             qt_set_error("qt_xtx_accumulate: internal tile table size mismatch");
             return QT_ERR_INVALID;
@@ -327,11 +334,10 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     p.n_splits = pl.n_splits;
     p.slabs = slabs;
     p.tile_tab = tile_tab;
-    static int map_mode = -1;
-    if (map_mode < 0) {
+    static const int map_mode = [] {
         const char* e = getenv("QT_XTX_MAP");
-        map_mode = e ? atoi(e) : 0;
-    }
+        return e ? atoi(e) : 0;
+    }();
     p.map_mode = map_mode;
     p.tiles_per_xcd = (pl.n_tiles + 7) / 8;
     const int grid = (map_mode == 2) ? 8 * p.tiles_per_xcd * pl.n_splits : pl.n_tiles * pl.n_splits;
