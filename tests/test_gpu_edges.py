@@ -92,3 +92,55 @@ def test_llama3_70b_down_proj_hessian_size(ops, dev):
     Qt, loss = ops.gptq_sweep(W.clone(), U, st, zt, g_idx, 128, 4)
     torch.cuda.synchronize()
     assert int(Qt.min()) >= -8 and int(Qt.max()) <= 7 and bool(torch.isfinite(loss).all())
+
+
+def test_entry_points_from_two_host_threads_on_two_streams(dev):
+    """The C ABI is re-entrant per stream: two host threads, each with its own HIP stream, quantise
+    different Linears at the same time and get the bytes a single-threaded run gets."""
+    import threading
+
+    from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_linear
+    from quantool_amd.engine.schemes import QuantArgs
+
+    def job(seed, stream=None):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        K = 384 if seed % 2 else 512
+        X = torch.randn((3, 200, K), generator=g).to(torch.bfloat16).to(dev)
+        W = (torch.randn((72, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
+        torch.cuda.synchronize()
+
+        def run():
+            acc = HessianAccumulator(K, dev)
+            acc.add(X)
+            r = gptq_quantize_linear(W, acc, QuantArgs(actorder="static"))
+            return r.weight_packed.clone(), r.weight_scale.clone()
+
+        if stream is None:
+            out = run()
+        else:
+            with torch.cuda.stream(stream):
+                out = run()
+            stream.synchronize()
+        return out
+
+    want = {seed: job(seed) for seed in (1, 2)}
+    torch.cuda.synchronize()
+    got, errors = {}, []
+
+    def worker(seed):
+        try:
+            torch.cuda.set_device(dev)
+            for _ in range(3):
+                got[seed] = job(seed, torch.cuda.Stream(device=dev))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(seed,)) for seed in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for seed in (1, 2):
+        assert torch.equal(got[seed][0], want[seed][0]) and torch.equal(got[seed][1], want[seed][1])
