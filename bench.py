@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
     ap.add_argument("--lanes", type=int, default=2, help="layers in flight (independent stream sets)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
+    ap.add_argument("--actorder", choices=["static", "group", "none"], default="static",
+                    help="activation ordering (default: upstream's default, static); other values are diagnostics")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,7 +224,8 @@ def main():
     lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
     shape = MODEL_SHAPES[MODEL]
     n_tokens = args.samples * SEQ_LEN
-    qargs = QuantArgs(num_bits=4, symmetric=True, group_size=128, actorder="static")
+    qargs = QuantArgs(num_bits=4, symmetric=True, group_size=128,
+                      actorder=None if args.actorder == "none" else args.actorder)
 
     weights, acts = {}, {}
     for gi, (gname, K, lins) in enumerate(shape.groups):
@@ -323,7 +326,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {
-                "workload": ("Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder=static, "
+                "workload": (f"Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, "
                              "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
                              "1 decoder layer (7 Linears, 218103808 weights) per step per GPU"),
                 "n_calibration_samples": args.samples, "seq_len": SEQ_LEN,
