@@ -24,6 +24,11 @@ struct SgemmArgs {
     // Never used when bit-exact k order matters (the caller passes nullptr there).
     float* split_ws = nullptr;
     size_t split_ws_bytes = 0;
+    // MODE_SUB only: when > 0 (a multiple of 16) the k range is a sequence of chains of this length
+    // and Cout = (((Cin - chain_0) - chain_1) - ...), every chain an ascending-k fmaf chain from 0 --
+    // bit for bit what chain-many separate launches would leave in C, with C read and written once
+    // (the GPTQ sweep's far update over several 128-column blocks).
+    int chain_len = 0;
     // internal (set by qt_sgemm_tn)
     int k_chunk = 0;
 };

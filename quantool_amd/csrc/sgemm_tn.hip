@@ -9,8 +9,11 @@ namespace {
 constexpr int BK = 16;
 constexpr int NT = 256;
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {  // p is modified per z-slice
+// amdgpu_waves_per_eu(2): the MODE_SUB variants hold a C tile next to the accumulators; capping the
+// register budget at two waves per SIMD makes hipcc park the excess in AGPRs instead of taking all
+// 512 registers (one wave per SIMD leaves the C read / write phases of a workgroup uncovered).
+template <int BM, int BN, int MODE, bool CHAIN = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sgemm_tn_kernel(SgemmArgs p) {  // p is modified per z-slice
     constexpr int WM = BM / 64, WN = BN / 64;  // 32x32 sub-tiles per wave in m / n
     constexpr int A4 = BK * BM / 4 / NT;       // float4 loads per thread for A
     constexpr int B4 = BK * BN / 4 / NT;
@@ -135,6 +138,21 @@ __global__ __launch_bounds__(NT) void sgemm_tn_kernel(SgemmArgs p) {  // p is mo
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             if (s + 1 < nsteps) lstore(buf ^ 1);
+            if (CHAIN && s + 1 < nsteps && ((s + 1) * BK) % p.chain_len == 0) {
+                // end of a chain: fold it into the C registers and start the next one from zero
+                // (one 32x32 accumulator at a time, so only 16 extra registers are live)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            cpre[i][j][r] = cpre[i][j][r] - acc[i][j][r];
+                            acc[i][j][r] = 0.0f;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
             __syncthreads();
         }
     }
@@ -190,7 +208,10 @@ int launch(const SgemmArgs& a, hipStream_t stream, int splits = 1) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     switch (a.mode) {
         case SG_MODE_SUB:
-            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB>), grid, dim3(NT), 0, stream, a);
+            if (a.chain_len > 0)
+                hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB, true>), grid, dim3(NT), 0, stream, a);
+            else
+                hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB>), grid, dim3(NT), 0, stream, a);
             break;
         case SG_MODE_SET:
             hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SET>), grid, dim3(NT), 0, stream, a);

@@ -11,6 +11,8 @@
 //   sgemm_tn (SUB)     : W[:, i2:] -= Err1 @ U[i1:i2, i2:] as an ascending-k fmaf chain from 0
 //                        on the f32 MFMA, then one subtraction -- the oracle's fixed order.
 // Bit-exact against oracle/gptq_oracle.c:orc_gptq_sweep.
+#include <stdlib.h>
+
 #include "common.h"
 #include "sgemm_tn.h"
 
@@ -19,6 +21,7 @@
 namespace {
 
 constexpr int BS = 128;    // upstream block_size default
+constexpr int SWEEP_MAX_BATCH = 4;  // blocks whose far update may be merged into one pass over W
 constexpr int SB = 32;     // register sub-block
 constexpr int ROWS = 128;  // rows (lanes) per workgroup: 2 waves
 constexpr size_t SWEEP_LDS = (size_t)(BS * BS + BS * ROWS + 2 * BS) * sizeof(float);
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
 extern "C" size_t qt_gptq_sweep_workspace_bytes(int R, int K, int blocksize) {
     (void)K;
     if (R <= 0 || blocksize <= 0) return 0;
-    return (size_t)blocksize * R * 4 + 256;  // ErrT[blocksize][R]
+    return (size_t)SWEEP_MAX_BATCH * blocksize * R * 4 + 256;  // ErrT[batch][blocksize][R]
 }
 
 extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float* scale_t, const float* zp_t, int G,
@@ -178,21 +181,45 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
                                    (int)SWEEP_LDS);
     }));
     QT_HIP(hipMemsetAsync(loss, 0, (size_t)R * 4, stream));
-    for (int i1 = 0; i1 < K; i1 += BS) {
-        const int i2 = (i1 + BS < K) ? i1 + BS : K;
-        const int cnt = i2 - i1;
-        qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
-        hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R, K, U,
-                           scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, ErrT, loss);
-        qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
-        QT_LAUNCH_CHECK();
-        if (i2 < K) {
+    // Lazy far update: the blocks of a batch update only the batch's own later columns right away
+    // (k = 128, few columns); everything to the right of the batch gets the batch's chains in ONE
+    // pass over W (chain_len = 128: same roundings, in the same order, as one pass per block), so
+    // the read-modify-write traffic on W drops by the batch size.
+    static const int batch_blocks = [] {
+        const char* e = getenv("QT_SWEEP_BATCH");
+        const int b = e ? atoi(e) : 2;
+        return b < 1 ? 1 : (b > SWEEP_MAX_BATCH ? SWEEP_MAX_BATCH : b);
+    }();
+    for (int b0 = 0; b0 < K; b0 += BS * batch_blocks) {
+        const int bend = (b0 + BS * batch_blocks < K) ? b0 + BS * batch_blocks : K;   // first column right of the batch
+        for (int i1 = b0; i1 < bend; i1 += BS) {
+            const int i2 = (i1 + BS < K) ? i1 + BS : K;
+            const int cnt = i2 - i1;
+            float* err_blk = ErrT + (size_t)(i1 - b0) * R;
+            qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
+            hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R,
+                               K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss);
+            qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
+            QT_LAUNCH_CHECK();
+            if (i2 < bend) {   // near update: the rest of this batch
+                SgemmArgs g;
+                g.A = err_blk; g.lda = R;
+                g.B = U + (size_t)i1 * K + i2; g.ldb = K;
+                g.Cin = W + i2; g.ldcin = K;
+                g.Cout = W + i2; g.ldcout = K;
+                g.M = R; g.N = bend - i2; g.kdim = cnt; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+                const int rc = qt_sgemm_tn(g, stream);
+                if (rc) return rc;
+            }
+        }
+        if (bend < K) {        // far update: every chain of the batch, one pass
             SgemmArgs g;
             g.A = ErrT; g.lda = R;
-            g.B = U + (size_t)i1 * K + i2; g.ldb = K;
-            g.Cin = W + i2; g.ldcin = K;
-            g.Cout = W + i2; g.ldcout = K;
-            g.M = R; g.N = K - i2; g.kdim = cnt; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+            g.B = U + (size_t)b0 * K + bend; g.ldb = K;
+            g.Cin = W + bend; g.ldcin = K;
+            g.Cout = W + bend; g.ldcout = K;
+            g.M = R; g.N = K - bend; g.kdim = bend - b0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+            g.chain_len = BS;
             const int rc = qt_sgemm_tn(g, stream);
             if (rc) return rc;
         }

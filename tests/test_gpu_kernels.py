@@ -200,7 +200,10 @@ def _sweep_case(oracle, R, K, gs, sym, actorder, seed):
 
 
 @pytest.mark.parametrize("R,K,gs,sym", [(16, 128, 128, True), (64, 256, 128, True), (130, 384, 128, True),
-                                        (200, 640, 128, False), (96, 200, -1, True), (257, 512, 64, True)])
+                                        (200, 640, 128, False), (96, 200, -1, True), (257, 512, 64, True),
+                                        # 9 blocks / 8 blocks + a ragged one: several far updates that carry
+                                        # more than one block's chain in a single pass over W (sweep.hip)
+                                        (40, 1152, 128, True), (48, 1100, -1, True)])
 def test_sweep_bit_exact_given_same_U(ops, oracle, dev, R, K, gs, sym):
     Wn, H = _sweep_case(oracle, R, K, gs, sym, None, seed=R + K)
     Hd, dead, _ = oracle.hessian_dead_and_damp(H)
