@@ -2,6 +2,8 @@
 // 32x32 MFMA accumulators.  Operand panels [BK][BM] / [BK][BN] are register-staged into a
 // double-buffered LDS image (rows contiguous, so fragment reads are conflict-free b32 reads of
 // 32 consecutive floats per lane half) and zero-filled at every edge, so any M, N, k works.
+#include <stdlib.h>
+
 #include "sgemm_tn.h"
 
 namespace {
@@ -240,12 +242,24 @@ int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream) {
     // Latency-bound shape (fewer 128x128 tiles than CUs, long k): keep the MFMA-dense 128x128
     // tile and split k over workgroups to fill the chip; slabs are reduced in ascending order.
     if (a.split_ws && t128 < 384 && a.kdim >= 512) {
-        // aim at ~2 workgroups per CU: the partner hides the other's barrier / global-load stalls
-        int splits = (int)(512 / t128);
+        // Aim at ~8 workgroups per CU (the SET kernel fits 4 per CU at a time): measured on the
+        // Cholesky chain, K = 14336: 44.2 / 39.5 / 37.3 / 37.9 ms at 512 / 1024 / 2048 / 3072 target
+        // workgroups -- the extra slab traffic costs less than the exposed barrier / load stalls.
+        static const int target_wgs = [] {
+            const char* e = getenv("QT_SGEMM_SPLIT_TARGET");
+            const int v = e ? atoi(e) : 2048;
+            return v < 256 ? 256 : v;
+        }();
+        static const int min_chunk = [] {
+            const char* e = getenv("QT_SGEMM_SPLIT_MIN_CHUNK");
+            const int v = e ? atoi(e) : 128;
+            return v < 64 ? 64 : v;
+        }();
+        int splits = (int)(target_wgs / t128);
         if (splits > 32) splits = 32;
         int chunk = (a.kdim + splits - 1) / splits;
         chunk = (chunk + 63) / 64 * 64;  // whole BK steps
-        if (chunk < 256) chunk = 256;
+        if (chunk < min_chunk) chunk = min_chunk;
         splits = (a.kdim + chunk - 1) / chunk;
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
         if (splits >= 2 && need <= a.split_ws_bytes) {
