@@ -85,7 +85,11 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0)
             # stream slots per layer: "all4" = one per group; "two" = the largest-K group alone, the rest
             # share one stream (diagnostic knob; default all4)
             slot = gi if os.environ.get("QT_BENCH_GROUPING", "all4") == "all4" else min(gi, 1)
-            st = _STREAMS.setdefault((dev.index, lane, slot), torch.cuda.Stream(device=dev))
+            if (dev.index, lane, slot) not in _STREAMS:
+                # QT_BENCH_CHAIN_PRIO=1 (diagnostic): the chain streams at high priority
+                prio = -1 if os.environ.get("QT_BENCH_CHAIN_PRIO") == "1" else 0
+                _STREAMS[(dev.index, lane, slot)] = torch.cuda.Stream(device=dev, priority=prio)
+            st = _STREAMS[(dev.index, lane, slot)]
             st.wait_stream(main)
         else:
             st = main
