@@ -98,3 +98,99 @@ def allreduce_gram(G: torch.Tensor, n_samples: int, group=None):
     n = torch.tensor([int(n_samples)], dtype=torch.int64, device=G.device)
     dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     return int(n.item())
+
+
+# ---- partitioning B: one Linear group spread over the ranks ------------------------
+def _comm(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Tensor as the process group's backend wants it: device tensors for RCCL, host for gloo."""
+    import torch.distributed as dist
+
+    return t.cpu() if dist.get_backend(group) == "gloo" and t.is_cuda else t
+
+
+def row_slices(rows: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced [begin, end) row ranges, one per rank (the first ``rows % world`` ranks
+    take one extra row; a rank may get none when rows < world)."""
+    base, extra = divmod(rows, world)
+    out, r0 = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((r0, r0 + n))
+        r0 += n
+    return out
+
+
+def gptq_quantize_token_split(weights: Sequence[torch.Tensor], local_batches, qargs, *, group=None,
+                              block_size: int = 128, dampening_frac: float = 0.01,
+                              num_local_samples: int = None):
+    """Quantise the Linears that share one input when the calibration TOKENS of that input are
+    spread over the ranks -- the shape that balances a decoder layer whose down_proj alone is two
+    thirds of the work, and Llama-3-70B's K = 28672 group (partitioning B):
+
+    1. every rank accumulates X^T X over its own batches                      (no communication)
+    2. one all-reduce of the K x K partial Gram sums and of the sample counts (the exchange step)
+    3. every rank factorises the same Hessian -- replicated: 2/3 K^3 flop is cheaper than moving
+       the K^2 factor -- and sweeps only ITS rows of every weight (rows are independent given U)
+    4. one all-gather of the packed rows and their scales                     (the gather step)
+
+    Returns, on every rank, {"weight_packed": [R, K/8] int32 (or "weight_q" int8 for 8-bit),
+    "weight_scale", optional "weight_zero_point" / "weight_g_idx"} per weight, full height.
+    Results are bit-identical to a single-rank run on a Gram matrix summed in the same order
+    (for two ranks: G0 + G1), which is what ``tests/test_gpu_token_split.py`` checks."""
+    import torch.distributed as dist
+
+    from .gptq_linear import HessianAccumulator, gptq_quantize_shared
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    K = int(weights[0].shape[1])
+    dev = weights[0].device
+    acc = HessianAccumulator(K, dev)
+    for xb in local_batches:
+        acc.add(xb.to(dev))
+    if num_local_samples is not None:
+        acc.n = int(num_local_samples)
+    g = _comm(acc.G, group)
+    n_total = allreduce_gram(g, acc.n, group)
+    if g is not acc.G:
+        acc.G.copy_(g)
+    acc.n = n_total
+
+    mine = [row_slices(int(w.shape[0]), world)[rank] for w in weights]
+    local = [w[b:e] for w, (b, e) in zip(weights, mine) if e > b]
+    res = iter(gptq_quantize_shared(local, acc, qargs, block_size=block_size, dampening_frac=dampening_frac)
+               if local else [])
+    out = []
+    for w, (b, e) in zip(weights, mine):
+        r = next(res) if e > b else None
+        R = int(w.shape[0])
+        slices = row_slices(R, world)
+        tallest = max(eb - bb for bb, eb in slices)
+        parts = {}
+        for key in ("weight_packed", "weight_q", "weight_scale", "weight_zero_point"):
+            mine_t = getattr(r, key, None) if r is not None else None
+            metas = [None] * world
+            dist.all_gather_object(metas, None if mine_t is None else
+                                   (int(mine_t.shape[1]), str(mine_t.dtype).replace("torch.", "")), group=group)
+            ref = next((m for m in metas if m is not None), None)
+            if ref is None:
+                continue                                   # nobody has this tensor (e.g. symmetric: no zero point)
+            # all_gather wants equal shapes: every rank sends `tallest` rows, the tail is padding
+            send = torch.zeros((tallest, ref[0]), dtype=getattr(torch, ref[1]), device=dev)
+            if mine_t is not None:
+                send[:e - b] = mine_t
+            send = _comm(send, group)
+            bufs = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(bufs, send, group=group)
+            parts[key] = torch.cat([buf[:eb - bb] for buf, (bb, eb) in zip(bufs, slices)], 0).to(dev)
+        if str(qargs.actorder).lower() == "group":
+            # the same on every rank that swept rows; ranks without rows get it from the first that did
+            g_idx = r.weight_g_idx if r is not None else None
+            if any(eb == bb for bb, eb in slices):
+                holder = [None if g_idx is None else g_idx.cpu()]
+                src = next(k for k, (bb, eb) in enumerate(slices) if eb > bb)
+                dist.broadcast_object_list(holder, src=src, group=group)
+                g_idx = holder[0].to(dev)
+            parts["weight_g_idx"] = g_idx
+        parts["weight_shape"] = torch.tensor([R, K], dtype=torch.int64)
+        out.append(parts)
+    return out

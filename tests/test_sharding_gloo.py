@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from quantool_amd.engine.sharding import allreduce_gram, gather_state_dict, group_cost, lpt_assign, my_units
+from quantool_amd.engine.sharding import (allreduce_gram, gather_state_dict, group_cost, lpt_assign, my_units,
+                                          row_slices)
 
 
 def test_lpt_assignment_is_balanced_and_deterministic():
@@ -78,3 +79,12 @@ def test_gather_state_dict_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def test_row_slices_cover_every_row_once():
+    for rows, world in [(10, 4), (2, 4), (4096, 8), (1, 2), (37, 2)]:
+        sl = row_slices(rows, world)
+        assert len(sl) == world and sl[0][0] == 0 and sl[-1][1] == rows
+        assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+        sizes = [e - b for b, e in sl]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
