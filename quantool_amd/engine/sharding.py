@@ -1,4 +1,8 @@
-"""Multi-GPU sharding of the per-Linear work (partitioning A).
+"""Multi-GPU sharding of the per-Linear work.
+
+Partitioning A (first half of this file): whole units per rank.  Partitioning B (second half,
+``gptq_quantize_token_split``): one Linear group spread over the ranks, with the path's one real
+exchange step -- the all-reduce of the partial Gram sums.
 
 Every Linear group's {X^T X, factorisation, sweep, pack} is independent given its activations, so
 units are assigned to ranks up front (LPT-greedy on a K^2*(N+R) cost) and processed with no
