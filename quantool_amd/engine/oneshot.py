@@ -117,7 +117,11 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
     smoothing_scales: Dict[str, torch.Tensor] = {}
     if gp is not None:
         qargs = gp.weight_args()
-        for g in cal.groups:
+        from .streams import GroupStreams
+
+        pool = GroupStreams(device)
+
+        def do_group(g):
             weights = {n: w.to(device) for n, w in g.weights.items()}
             rescale = None
             if sq is not None and g.smooth_vectors:
@@ -127,7 +131,7 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
                 smoothing_scales[g.name] = rescale
             names = [n for n in weights if n.split(".")[-1] not in gp.ignore and n not in gp.ignore]
             if not names:
-                continue
+                return
             K = weights[names[0]].shape[1]
             acc = HessianAccumulator(K, device)
             for xb in _iter_batches(g.activations):
@@ -140,6 +144,11 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
             res = gptq_quantize_shared([weights[n] for n in names], acc, qargs,
                                        block_size=gp.block_size, dampening_frac=gp.dampening_frac)
             results.update(dict(zip(names, res)))
+
+        # one stream per group, largest in_features first (longest chain): see streams.py
+        for g in sorted(cal.groups, key=lambda g: -int(next(iter(g.weights.values())).shape[1])):
+            pool.run(lambda g=g: do_group(g))
+        pool.join()
         mod = gp
     else:
         from .awq_linear import awq_quantize_group

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from .gptq_linear import HessianAccumulator, gptq_quantize_shared
 from .modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
+from .streams import GroupStreams
 
 logger = logging.getLogger(__name__)
 
@@ -201,14 +202,21 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 layer(*args, **kwargs)
             for hk in hooks:
                 hk.remove()
-            for lead, names in leaders.items():
+            # one stream per input group, largest in_features first (longest chain): see streams.py
+            pool = GroupStreams(dev)
+
+            def quantize_group(lead, names):
                 ws = [linears[n].weight.data for n in names]
                 res = gptq_quantize_shared(ws, accs[lead], qargs, block_size=gp.block_size,
                                            dampening_frac=gp.dampening_frac)
                 for n, r in zip(names, res):
                     linears[n].weight.data.copy_(r.dequantized(linears[n].weight.dtype))
                     results[n] = r
-                del accs[lead]
+
+            for lead, names in sorted(leaders.items(), key=lambda kv: -linears[kv[0]].in_features):
+                pool.run(lambda lead=lead, names=names: quantize_group(lead, names))
+            pool.join()
+            accs.clear()
             cache = _advance(layer, cache)
             logger.info(f"quantized {lname}: {len(linears)} Linears in {len(leaders)} input groups")
     model._qt_results = results
