@@ -131,7 +131,7 @@ int qt_dequantize(const int8_t* Qt, int R, int K, const int32_t* col_src, const 
 
 /* ---- a12  AWQ scale search (AWQModifier under awq.py:81) ----------------------------------------
  * w_sum[K] += sum_rows |w| / (group absmax + 1e-6) (call once per balance layer; w_mean = w_sum /
- * total rows).  group_size: multiple of 64, <= 512, dividing K. */
+ * total rows).  group_size: any divisor of K; <= 0 = one group per row (W8A16). */
 size_t qt_awq_weight_mean_workspace_bytes(int R, int K);
 int qt_awq_weight_mean_accumulate(const void* W, int w_dtype, int R, int K, int64_t ldw, int group_size,
                                   float* w_sum, void* workspace, size_t workspace_bytes,

@@ -63,6 +63,34 @@ __global__ __launch_bounds__(64) void awq_wmean_partial_kernel(const void* __res
         if (e < per) partial[(size_t)chunk * K + (size_t)g * gs + e * 64 + lane] = acc[e];
 }
 
+// Long groups (group_size > 512, channel-wise included): the per-lane register arrays above do not
+// scale, so the group maxima come first (one wave per (row, group), lanes striding the group) and the
+// column sums are then taken one thread per column over a chunk of rows.
+__global__ __launch_bounds__(64) void row_group_absmax_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                              int64_t ldw, int gs, float* __restrict__ amax) {
+    const int g = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    float m = 0.0f;
+    for (int c = lane; c < gs; c += 64) m = fmaxf(m, fabsf(load_w(W, dtype, (size_t)r * ldw + (size_t)g * gs + c)));
+    m = wave_max(m);
+    if (lane == 0) amax[(size_t)r * (K / gs) + g] = m;
+}
+
+__global__ __launch_bounds__(256) void awq_wmean_cols_kernel(const void* __restrict__ W, int dtype, int R, int K,
+                                                             int64_t ldw, int gs, const float* __restrict__ amax,
+                                                             float* __restrict__ partial) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int chunk = blockIdx.y;
+    if (k >= K) return;
+    const int G = K / gs, g = k / gs;
+    const int r0 = chunk * WM_ROWS, r1 = (r0 + WM_ROWS < R) ? r0 + WM_ROWS : R;
+    float acc = 0.0f;
+    for (int r = r0; r < r1; ++r) {
+        const float m = amax[(size_t)r * G + g] + 1e-6f;
+        acc = acc + fabsf(load_w(W, dtype, (size_t)r * ldw + k)) / m;
+    }
+    partial[(size_t)chunk * K + k] = acc;
+}
+
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ partial, int n_chunks, int K,
                                                         float* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +151,45 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
                                                               int symmetric, int num_bits, void* __restrict__ out,
                                                               int64_t ldo) {
     const int g = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
-    const int per = gs / 64;
+    const int per = (gs + 63) / 64;
+    if (per > 8 || (gs & 63)) {
+        // long or odd-sized group (channel-wise: the whole row): two passes over the group, the second one out of L2
+        float mx = -INFINITY, mn = INFINITY, amax = 0.0f;
+        for (int c = lane; c < gs; c += 64) {
+            const int k = g * gs + c;
+            const float v = load_w(W, dtype, (size_t)r * ldw + k) * s[k];
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+            amax = fmaxf(amax, fabsf(v));
+        }
+        mx = wave_max(mx);
+        mn = wave_min(mn);
+        amax = wave_max(amax);
+        for (int c = lane; c < gs; c += 64) {
+            const int k = g * gs + c;
+            const float wv = load_w(W, dtype, (size_t)r * ldw + k);
+            const float v = wv * s[k];
+            float q;
+            if (symmetric) {
+                const float max_int = (float)((1 << (num_bits - 1)) - 1), min_int = -(float)(1 << (num_bits - 1));
+                const float sc = fmaxf(amax, 1e-5f) / max_int;
+                q = fminf(fmaxf(rintf(v / sc), min_int), max_int) * sc;
+            } else {
+                const float max_int = (float)((1 << num_bits) - 1);
+                const float sc = fmaxf(mx - mn, 1e-5f) / max_int;
+                const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
+                q = (fminf(fmaxf(rintf(v / sc) + z, 0.0f), max_int) - z) * sc;
+            }
+            if (DIFF) {
+                ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(wv - q / s[k]);
+            } else if (dtype == QT_F32) {
+                ((float*)out)[(size_t)r * ldo + k] = q / s[k];
+            } else {
+                ((__bf16*)out)[(size_t)r * ldo + k] = (__bf16)(q / s[k]);
+            }
+        }
+        return;
+    }
     float w[8], ws[8];
     float mx = -INFINITY, mn = INFINITY, amax = 0.0f;
 #pragma unroll
@@ -281,7 +347,8 @@ __global__ __launch_bounds__(256) void rtn_kernel(const void* __restrict__ W, in
 
 extern "C" size_t qt_awq_weight_mean_workspace_bytes(int R, int K) {
     if (R <= 0 || K <= 0) return 0;
-    return (size_t)((R + WM_ROWS - 1) / WM_ROWS) * K * 4 + 256;
+    // per-chunk partial sums + (long groups only) one maximum per (row, group); K / 64 bounds the groups
+    return (size_t)((R + WM_ROWS - 1) / WM_ROWS) * K * 4 + qt_align_up((size_t)R * ((K + 63) / 64) * 4, 256) + 512;
 }
 
 extern "C" int qt_awq_weight_mean_accumulate(const void* W, int w_dtype, int R, int K, int64_t ldw, int group_size,
@@ -291,8 +358,8 @@ extern "C" int qt_awq_weight_mean_accumulate(const void* W, int w_dtype, int R, 
     QT_CHECK_ARG(W && w_sum && R > 0 && K > 0, "qt_awq_weight_mean_accumulate: bad arguments");
     QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_awq_weight_mean_accumulate: dtype");
     const int gs = group_size <= 0 ? K : group_size;
-    if (K % gs != 0 || gs % 64 != 0 || gs > 512) {
-        qt_set_error("qt_awq_weight_mean_accumulate: group_size %d unsupported (multiple of 64, <= 512, dividing K)", gs);
+    if (K % gs != 0) {
+        qt_set_error("qt_awq_weight_mean_accumulate: group_size %d does not divide K", gs);
         return QT_ERR_UNSUPPORTED;
     }
     const size_t need = qt_awq_weight_mean_workspace_bytes(R, K);
@@ -302,9 +369,20 @@ extern "C" int qt_awq_weight_mean_accumulate(const void* W, int w_dtype, int R, 
     }
     float* partial = (float*)qt_align_up((size_t)workspace, 256);
     const int chunks = (R + WM_ROWS - 1) / WM_ROWS;
-    hipLaunchKernelGGL(awq_wmean_partial_kernel, dim3(K / gs, chunks), dim3(64), 0, stream, W, w_dtype, R, K, ldw, gs,
-                       partial);
-    QT_LAUNCH_CHECK();
+    if (gs <= 512 && gs % 64 == 0) {
+        hipLaunchKernelGGL(awq_wmean_partial_kernel, dim3(K / gs, chunks), dim3(64), 0, stream, W, w_dtype, R, K, ldw,
+                           gs, partial);
+        QT_LAUNCH_CHECK();
+    } else {
+        QT_CHECK_ARG(R <= 65535, "qt_awq_weight_mean_accumulate: R=%d > 65535 rows per call with long groups", R);
+        float* amax = partial + (size_t)chunks * K;
+        hipLaunchKernelGGL(row_group_absmax_kernel, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, gs,
+                           amax);
+        QT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(awq_wmean_cols_kernel, dim3((K + 255) / 256, chunks), dim3(256), 0, stream, W, w_dtype, R,
+                           K, ldw, gs, (const float*)amax, partial);
+        QT_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(chunk_sum_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, (const float*)partial, chunks, K,
                        w_sum);
     QT_LAUNCH_CHECK();
@@ -344,7 +422,7 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
     QT_CHECK_ARG(W && s && Gfull && loss_out && R > 0 && K > 0 && n_tokens > 0, "qt_awq_loss: bad arguments");
     QT_CHECK_ARG(K % 8 == 0, "qt_awq_loss: K=%d must be a multiple of 8", K);
     const int gs = group_size <= 0 ? K : group_size;
-    if (K % gs != 0 || gs % 64 != 0 || gs > 512) {
+    if (K % gs != 0) {
         qt_set_error("qt_awq_loss: group_size %d unsupported", gs);
         return QT_ERR_UNSUPPORTED;
     }
@@ -382,7 +460,7 @@ extern "C" int qt_awq_pseudo_quantize(const void* W, int w_dtype, int R, int K, 
     QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_awq_pseudo_quantize: dtype %d unsupported", w_dtype);
     QT_CHECK_ARG(num_bits >= 2 && num_bits <= 8, "qt_awq_pseudo_quantize: num_bits=%d", num_bits);
     const int gs = group_size <= 0 ? K : group_size;
-    if (K % gs != 0 || gs % 64 != 0 || gs > 512) {
+    if (K % gs != 0) {
         qt_set_error("qt_awq_pseudo_quantize: group_size %d unsupported", gs);
         return QT_ERR_UNSUPPORTED;
     }

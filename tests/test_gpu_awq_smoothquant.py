@@ -59,6 +59,43 @@ def test_awq_two_balance_layers_and_asym(dev, oracle):
     assert int(best.item()) == r["best_ratio_idx"]
 
 
+@pytest.mark.parametrize("K", [1024, 448, 200])
+def test_awq_channelwise_w8a16(dev, oracle, K):
+    """AWQ's third level, W8A16: 8-bit, one group per row (group = K: the register path up to 512 when K is a
+    multiple of 64, the two-pass long-group path otherwise)."""
+    from quantool_amd.engine.awq_linear import awq_quantize_group, awq_search
+    from quantool_amd.engine.schemes import preset_name_to_scheme
+    from quantool_amd.hip import ops
+
+    rng = np.random.default_rng(8)
+    N = 512
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    X[:, 3::97] *= 12
+    xb = oracle.f32_to_bf16_bits(X)
+    W1, W2 = synth_weight(40, K, 4, 0.05), synth_weight(24, K, 5, 0.05)
+    qa = preset_name_to_scheme("W8A16").weights
+    assert qa.kernel_group_size <= 0 and qa.num_bits == 8
+    r = oracle.awq_best_scale(xb, [W1, W2], -1, symmetric=True, num_bits=8)
+    t1, t2 = torch.from_numpy(W1).to(dev), torch.from_numpy(W2).to(dev)
+    scales, losses, best, _ = awq_search([t1, t2], [bits_to_bf16_tensor(xb, dev)], qa)
+    torch.cuda.synchronize()
+    o_scales = np.stack([oracle.awq_scales_for_ratio(r["x_mean"], r["w_mean"], i / 20) for i in range(20)])
+    np.testing.assert_allclose(scales.cpu().numpy(), o_scales, rtol=2e-5)
+    # 8-bit errors are tiny: D rounded to bf16 still carries them to ~3 digits
+    np.testing.assert_allclose(losses.cpu().numpy(), r["losses"], rtol=1e-2)
+    assert int(best.item()) == r["best_ratio_idx"] or \
+        abs(r["losses"][int(best.item())] - r["losses"].min()) < 1e-2 * r["losses"].min()
+    # trial weights of one grid point, bit for bit
+    s5 = scales[5].contiguous()
+    got = ops.awq_pseudo_quantize(t1, s5, -1, True, 8).cpu().numpy()
+    sn = s5.cpu().numpy()
+    want = (oracle.awq_pseudo_quantize((W1 * sn[None, :]).astype(np.float32), -1, True, 8) / sn[None, :]).astype(np.float32)
+    np.testing.assert_array_equal(got, want)
+    res = awq_quantize_group([t1, t2], [bits_to_bf16_tensor(xb, dev)], qa)
+    torch.cuda.synchronize()
+    assert res[0].weight_packed is None and res[0].weight_q.dtype == torch.int8 and res[0].weight_scale.shape == (40, 1)
+
+
 def test_smoothquant_scales_and_apply(dev, oracle):
     from quantool_amd.engine.smoothquant import ChannelMinMax, apply_smoothing, smoothquant_scales
 
