@@ -42,11 +42,32 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
     const bool valid = row < R;
     const int rowc = valid ? row : R - 1;
 
-    for (int e = tid; e < BS * BS; e += ROWS) {
-        const int i = e / BS, j = e % BS;
-        float v = 0.0f;
-        if (i < cnt && j < cnt && j >= i) v = U[(size_t)(i1 + i) * K + (i1 + j)];
-        Un[e] = v;
+    // Prologue loads are issued in batches of 16 independent float4 loads per thread and only then
+    // written to LDS: a load -> wait -> store loop costs one memory round trip per iteration (32 + 128
+    // of them used to be half of this kernel's time).  Out-of-block elements of a ragged last block are
+    // read from a clamped in-block address and replaced by the inert value afterwards (cnt % 4 == 0
+    // because K % 4 == 0, so a float4 is either wholly inside or wholly outside).
+    {
+        const float* ublk = U + (size_t)i1 * K + i1;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e4 = tid + ROWS * (half * 16 + r);      // float4 index in the 128 x 32 grid
+                const int i = e4 >> 5, j = (e4 & 31) * 4;
+                const int ic = i < cnt ? i : cnt - 1, jc = j < cnt ? j : cnt - 4;
+                v[r] = *(const f32x4*)(ublk + (size_t)ic * K + jc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e4 = tid + ROWS * (half * 16 + r);
+                const int i = e4 >> 5, j = (e4 & 31) * 4;
+                const bool inside = i < cnt && j < cnt;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Un[i * BS + j + q] = (inside && j + q >= i) ? v[r][q] : 0.0f;
+            }
+        }
     }
     {
         const float d = (tid < cnt) ? U[(size_t)(i1 + tid) * K + (i1 + tid)] : 1.0f;
@@ -55,17 +76,20 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
     }
     {
         const float* wrow = W + (size_t)rowc * K + i1;
-        for (int c = 0; c < BS; c += 4) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (c + 3 < cnt) {
-                v = *(const f32x4*)(wrow + c);
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c + e < cnt) v[e] = wrow[c + e];
+        for (int half = 0; half < 2; ++half) {
+            f32x4 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = (half * 16 + r) * 4;
+                v[r] = *(const f32x4*)(wrow + (c < cnt ? c : cnt - 4));
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) wl[(c + e) * ROWS + tid] = v[e];
+            for (int r = 0; r < 16; ++r) {
+                const int c = (half * 16 + r) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wl[(c + q) * ROWS + tid] = (c < cnt) ? v[r][q] : 0.0f;
+            }
         }
     }
     __syncthreads();
