@@ -72,7 +72,7 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
     {
         const float d = (tid < cnt) ? U[(size_t)(i1 + tid) * K + (i1 + tid)] : 1.0f;
         dd[tid] = d;
-        dd[BS + tid] = d * d;
+        dd[BS + tid] = 1.0f / (d * d);   // only the loss uses it (tolerance 1e-6, not part of the bit-exact contract)
     }
     {
         const float* wrow = W + (size_t)rowc * K + i1;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
         for (int t = 0; t < SB; ++t) {
             const int c = cb + t;
             {  // columns >= cnt of a ragged last block run as inert padding (w=0, U=0, d=1)
-                const float d = dd[c], d2 = dd[BS + c];
+                const float d = dd[c], rd2 = dd[BS + c];
                 const float wv = w[t];
                 float x = wv / sc[t];
                 x = x + zz[t];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
                 const float q = rintf(x);
                 const float dq = (q - zz[t]) * sc[t];
                 const float diff = wv - dq;
-                blk_loss = blk_loss + (diff * diff) / d2;
+                blk_loss = blk_loss + (diff * diff) * rd2;
                 const float e = diff / d;
                 er[t] = e;
                 w[t] = dq;
@@ -129,10 +129,21 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
                     ErrT[(size_t)c * R + row] = e;
                 }
                 const float* urow = Un + c * BS + cb;
+                // two columns per instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE single
+                // operations, so the roundings are unchanged); an odd first column goes alone
+                if ((t + 1) & 1) {
+                    const float pr = e * urow[t + 1];
+                    w[t + 1] = w[t + 1] - pr;
+                }
+                const f32x2 e2 = {e, e};
 #pragma unroll
-                for (int u = t + 1; u < SB; ++u) {
-                    const float pr = e * urow[u];
-                    w[u] = w[u] - pr;
+                for (int u = (t + 2) & ~1; u < SB; u += 2) {
+                    const f32x2 uu = *(const f32x2*)(urow + u);
+                    const f32x2 pr = e2 * uu;
+                    f32x2 wp = {w[u], w[u + 1]};
+                    wp = wp - pr;
+                    w[u] = wp[0];
+                    w[u + 1] = wp[1];
                 }
             }
             // keep each column step's LDS broadcasts next to their use (without this hipcc
@@ -156,20 +167,21 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
         }
         // rank-32 update of the block's remaining columns (ascending source column per element)
         for (int j4 = cb + SB; j4 < cnt; j4 += 4) {
-            float wj[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wj[e] = wl[(j4 + e) * ROWS + tid];
+            f32x2 wa = {wl[(j4 + 0) * ROWS + tid], wl[(j4 + 1) * ROWS + tid]};
+            f32x2 wb = {wl[(j4 + 2) * ROWS + tid], wl[(j4 + 3) * ROWS + tid]};
 #pragma unroll
             for (int t = 0; t < SB; ++t) {
                 const f32x4 u = *(const f32x4*)(Un + (cb + t) * BS + j4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pr = er[t] * u[e];
-                    wj[e] = wj[e] - pr;
-                }
+                const f32x2 e2 = {er[t], er[t]};
+                const f32x2 ua = {u[0], u[1]}, ub = {u[2], u[3]};
+                const f32x2 pa = e2 * ua, pb = e2 * ub;
+                wa = wa - pa;
+                wb = wb - pb;
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wl[(j4 + e) * ROWS + tid] = wj[e];
+            wl[(j4 + 0) * ROWS + tid] = wa[0];
+            wl[(j4 + 1) * ROWS + tid] = wa[1];
+            wl[(j4 + 2) * ROWS + tid] = wb[0];
+            wl[(j4 + 3) * ROWS + tid] = wb[1];
         }
     }
     if (valid) loss[row] = loss[row] + blk_loss / 2.0f;
