@@ -223,7 +223,7 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
     // the read-modify-write traffic on W drops by the batch size.
     static const int batch_blocks = [] {
         const char* e = getenv("QT_SWEEP_BATCH");
-        const int b = e ? atoi(e) : 2;
+        const int b = e ? atoi(e) : 4;
         return b < 1 ? 1 : (b > SWEEP_MAX_BATCH ? SWEEP_MAX_BATCH : b);
     }();
     for (int b0 = 0; b0 < K; b0 += BS * batch_blocks) {
