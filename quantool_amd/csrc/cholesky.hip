@@ -71,12 +71,40 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* __restrict__ P,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
 
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        float v = (i == j) ? 1.0f : 0.0f;
-        if (hi < n) v = P[(size_t)lo * ldp + hi];  // symmetric fill from the upper triangle
-        As[i * LDA + j] = v;
+    // Symmetric fill from the upper triangle (identity padding beyond n).  The 16 row-major float4
+    // loads of a thread are all issued before the first is used: a load -> wait -> store loop pays one
+    // memory round trip per element (64 of them were ~40 % of this kernel).  Needs ldp % 4 == 0 (then
+    // n % 4 == 0 too: n is 128 or K % 128) and a 16-byte aligned P; odd K takes the scalar loop.
+    if ((ldp & 3) == 0 && (n & 3) == 0 && (((uintptr_t)P) & 15) == 0) {
+        f32x4 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e4 = tid + 256 * r;                 // float4 index in the 128 x 32 grid
+            const int i = e4 >> 5, j = (e4 & 31) * 4;
+            const int ic = i < n ? i : n - 1, jc = j < n ? j : n - 4;
+            v[r] = *(const f32x4*)(P + (size_t)ic * ldp + jc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e4 = tid + 256 * r;
+            const int i = e4 >> 5, j = (e4 & 31) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jj = j + q;
+                if (jj < i) continue;                     // lower triangle: written by its mirror
+                const float x = (i < n && jj < n) ? v[r][q] : (i == jj ? 1.0f : 0.0f);
+                As[i * LDA + jj] = x;
+                if (jj > i) As[jj * LDA + i] = x;
+            }
+        }
+    } else {
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            float v = (i == j) ? 1.0f : 0.0f;
+            if (hi < n) v = P[(size_t)lo * ldp + hi];
+            As[i * LDA + j] = v;
+        }
     }
     __syncthreads();
 
