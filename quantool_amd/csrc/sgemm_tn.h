@@ -31,6 +31,7 @@ struct SgemmArgs {
     int chain_len = 0;
     // internal (set by qt_sgemm_tn)
     int k_chunk = 0;
+    int fast_interior = 1;
 };
 
 // Enqueue on `stream`; picks the tile size from the problem shape.  Returns qt_status.

@@ -42,7 +42,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
 
     f32x4 ra[A4], rb[B4];
 
+    // whole tile inside the matrices and 16-byte loads legal: the k-steps that are also inside the
+    // k range take straight vector loads (no per-element edge tests in the steady state)
+    const bool interior = p.fast_interior && a_vec && b_vec && m0 + BM <= p.M && n0 + BN <= p.N;
     auto gload = [&](int k0) {
+        if (interior && k0 + BK <= k_end) {
+#pragma unroll
+            for (int r = 0; r < A4; ++r) {
+                const int idx = tid + NT * r;
+                ra[r] = *(const f32x4*)(p.A + (size_t)(k0 + idx / (BM / 4)) * p.lda + m0 + (idx % (BM / 4)) * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < B4; ++r) {
+                const int idx = tid + NT * r;
+                rb[r] = *(const f32x4*)(p.B + (size_t)(k0 + idx / (BN / 4)) * p.ldb + n0 + (idx % (BN / 4)) * 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < A4; ++r) {
             const int idx = tid + NT * r;
@@ -236,8 +252,14 @@ int qt_splitk_reduce(const float* slabs, int splits, int M, int N, const float* 
     return QT_OK;
 }
 
-int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream) {
-    if (a.M <= 0 || a.N <= 0) return QT_OK;
+int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
+    if (a_.M <= 0 || a_.N <= 0) return QT_OK;
+    static const int fast_interior = [] {
+        const char* e = getenv("QT_SGEMM_INTERIOR");
+        return (e && atoi(e) == 0) ? 0 : 1;
+    }();
+    SgemmArgs a = a_;
+    a.fast_interior = fast_interior;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     // Latency-bound shape (fewer 128x128 tiles than CUs, long k): keep the MFMA-dense 128x128
     // tile and split k over workgroups to fill the chip; slabs are reduced in ascending order.
