@@ -26,6 +26,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const bool tile_inside = p.fast_interior && m0 + BM <= p.M && n0 + BN <= p.N;   // wave-uniform
 
     int k_begin = 0;
     if (p.k_mode == SG_K_FROM_N0) k_begin = n0 / BK * BK;
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
     f32x4 ra[A4], rb[B4];
 
     // whole tile inside the matrices and 16-byte loads legal: the k-steps that are also inside the
-    // k range take straight vector loads (no per-element edge tests in the steady state)
+    // k range take straight vector loads (no per-element edge tests in the steady state); the C
+    // prefetch and the epilogue of such a tile skip their bounds tests too
     const bool interior = p.fast_interior && a_vec && b_vec && m0 + BM <= p.M && n0 + BN <= p.N;
     auto gload = [&](int k0) {
         if (interior && k0 + BK <= k_end) {
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wave_m * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
-                    cpre[i][j][r] = (row < p.M && col < p.N) ? p.Cin[(size_t)row * p.ldcin + col] : 0.0f;
+                    cpre[i][j][r] = (tile_inside || (row < p.M && col < p.N)) ? p.Cin[(size_t)row * p.ldcin + col] : 0.0f;
                 }
     }
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wave_m * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
-                if (row < p.M && col < p.N) {
+                if (tile_inside || (row < p.M && col < p.N)) {
                     float v = acc[i][j][r];
                     if (MODE == SG_MODE_SUB) v = cpre[i][j][r] - v;
                     if (MODE == SG_MODE_NEG) v = -v;
