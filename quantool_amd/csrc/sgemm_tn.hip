@@ -204,7 +204,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const size_t mn = (size_t)M * N;
     if (col + 3 < N && (N & 3) == 0) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < splits; ++z) s += *(const f32x4*)(slabs + z * mn + (size_t)row * N + col);
+        // loads in batches of 8 (independent, all in flight together), adds in ascending z: the sum
+        // order -- hence the result -- is that of the plain loop, without one memory round trip per slab
+        const float* src = slabs + (size_t)row * N + col;
+        int z = 0;
+        for (; z + 8 <= splits; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (size_t)(z + u) * mn);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < splits; ++z) s += *(const f32x4*)(src + (size_t)z * mn);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = s[e];
