@@ -64,9 +64,38 @@ def synth_weight(R: int, K: int, seed: int, device) -> torch.Tensor:
 
 
 _STREAMS = {}
+_ACCS = {}
 
 
-def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0):
+def _accumulator(K, dev, lane, slot):
+    """One accumulator (G + token staging buffer) per (lane, group), reused across steps like the
+    per-stream workspaces: all work on it is ordered on that group's stream."""
+    from quantool_amd.engine.gptq_linear import HessianAccumulator
+
+    key = (dev.index, lane, slot, K)
+    acc = _ACCS.get(key)
+    if acc is None:
+        acc = _ACCS[key] = HessianAccumulator(K, dev)
+    else:
+        acc.reset()
+    return acc
+
+
+def accumulate(acc, X, n_samples, per_sample):
+    """Feed the calibration activations of one Linear group to its Hessian accumulator: either as
+    ONE resident [N, K] batch (BASELINE.md 2.2's per-Linear microbenchmark) or the way the plugin
+    path delivers them -- one sample of SEQ_LEN tokens per call (reference base.py:161, batch size 1),
+    which `HessianAccumulator` stages into its device token buffer."""
+    if not per_sample:
+        acc.add(X, num_samples=n_samples)
+        return
+    T = X.shape[0] // n_samples
+    for i in range(n_samples):
+        acc.add(X[i * T:(i + 1) * T], num_samples=1)
+    acc.flush()
+
+
+def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0, per_sample=False):
     """One step: the hot path over one decoder layer.  Returns the packed outputs.
 
     The layer's Linear groups are independent, so each runs on its own HIP stream: the
@@ -104,14 +133,14 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0)
             sx = _STREAMS[key]
             sx.wait_stream(main)
             with torch.cuda.stream(sx):
-                acc = HessianAccumulator(K, dev)
-                acc.add(acts[gname], num_samples=n_samples)
+                acc = HessianAccumulator(K, dev)   # fresh: its later use is on another stream
+                accumulate(acc, acts[gname], n_samples, per_sample)
             acc.G.record_stream(st)
             st.wait_stream(sx)
         with torch.cuda.stream(st):
             if xmode == "group":
-                acc = HessianAccumulator(K, dev)
-                acc.add(acts[gname], num_samples=n_samples)
+                acc = _accumulator(K, dev, lane, gi)
+                accumulate(acc, acts[gname], n_samples, per_sample)
             res = gptq_quantize_shared([weights[n] for n, _ in lins], acc, qargs)
             for (lname, _), r in zip(lins, res):
                 outs[f"{lname}.weight_packed"] = r.weight_packed
@@ -195,6 +224,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
     ap.add_argument("--lanes", type=int, default=2, help="layers in flight (independent stream sets)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
+    ap.add_argument("--accumulate", choices=["single", "per-sample"], default="single",
+                    help="single: one resident [N, K] activation batch per Linear group (BASELINE.md 2.2); per-sample: "
+                         "512 calls of 384 tokens per group, the plugin path's calling pattern (staged on the device)")
     ap.add_argument("--actorder", choices=["static", "group", "none"], default="static",
                     help="activation ordering (default: upstream's default, static); other values are diagnostics")
     args = ap.parse_args()
@@ -243,8 +275,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    per_sample = args.accumulate == "per-sample"
     for _ in range(args.warmup):
-        quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap)
+        quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap, lane=_ % max(1, args.lanes),
+                       per_sample=per_sample)
     join_streams(dev)
     barrier()
 
@@ -254,7 +288,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kept.append(quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap,
-                                   lane=_ % max(1, args.lanes)))
+                                   lane=_ % max(1, args.lanes), per_sample=per_sample))
     t_enqueued = time.perf_counter() - t0      # host side done issuing; the device is still working
     join_streams(dev)
     if dist is not None:
@@ -335,7 +369,7 @@ def main():
                 "workload": (f"Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, "
                              "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
                              "1 decoder layer (7 Linears, 218103808 weights) per step per GPU"),
-                "n_calibration_samples": args.samples, "seq_len": SEQ_LEN,
+                "n_calibration_samples": args.samples, "seq_len": SEQ_LEN, "accumulate": args.accumulate,
                 "layers_per_step_per_gpu": 1, "sharding": f"layers over {world} rank(s), RCCL gather of packed state",
             },
             "roofline": roofline,

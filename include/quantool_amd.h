@@ -75,8 +75,9 @@ int qt_hessian_prepare(const float* G, int K, int64_t n_samples, float percdamp,
                        void* workspace, size_t workspace_bytes, qt_stream_t stream);
 /* diag(2/n * G) only (input to the activation-ordering argsort). */
 int qt_hessian_diag(const float* G, int K, int64_t n_samples, float* diag_out, qt_stream_t stream);
-/* a9: perm = argsort(values, descending), stable (equal values keep ascending index; NaNs are not
- * expected); inv (may be NULL) receives the inverse permutation.  Rank counting, deterministic. */
+/* a9: perm = argsort(values, descending), stable (equal values keep ascending index; NaN orders as
+ * the largest value, as torch.argsort does, so perm is a permutation for any input); inv (may be
+ * NULL) receives the inverse permutation.  Rank counting, deterministic. */
 int qt_argsort_desc(const float* values, int K, int32_t* perm, int32_t* inv, qt_stream_t stream);
 
 /* ---- a8  cholesky -> cholesky_inverse -> cholesky(upper) ------------------------------------

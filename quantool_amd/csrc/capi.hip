@@ -18,6 +18,7 @@ extern "C" int qt_version(void) { return 100; }
 // ---- optional per-kernel timing with HIP events (bench.py's roofline leg) ---------------------
 // Events are recorded on the launch stream immediately around the kernel, so the elapsed time is
 // that kernel's device duration, not the enclosing API call.
+#include <atomic>
 #include <vector>
 
 namespace {
@@ -25,12 +26,14 @@ struct ProfSlot {
     std::vector<hipEvent_t> ev;  // pairs
     size_t used = 0;
 };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mutex;  // the entry points may be called from several host threads (one per stream)
 ProfSlot g_prof[QT_PROF_NUM_KERNELS];
 }  // namespace
 
 void qt_prof_mark(int kernel_id, hipStream_t stream) {
-    if (!g_prof_on || kernel_id < 0 || kernel_id >= QT_PROF_NUM_KERNELS) return;
+    if (!g_prof_on.load(std::memory_order_relaxed) || kernel_id < 0 || kernel_id >= QT_PROF_NUM_KERNELS) return;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     ProfSlot& s = g_prof[kernel_id];
     if (s.used == s.ev.size()) {
         hipEvent_t e;
@@ -41,6 +44,7 @@ void qt_prof_mark(int kernel_id, hipStream_t stream) {
 }
 
 extern "C" int qt_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     g_prof_on = on != 0;
     for (int k = 0; k < QT_PROF_NUM_KERNELS; ++k) g_prof[k].used = 0;
     return QT_OK;
@@ -49,6 +53,7 @@ extern "C" int qt_profile_enable(int on) {
 extern "C" int qt_profile_read(int kernel_id, double* total_ms, int64_t* launches) {
     QT_CHECK_ARG(kernel_id >= 0 && kernel_id < QT_PROF_NUM_KERNELS && total_ms && launches,
                  "qt_profile_read: bad arguments");
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     ProfSlot& s = g_prof[kernel_id];
     double tot = 0.0;
     int64_t n = 0;

@@ -63,12 +63,15 @@ __global__ __launch_bounds__(256) void diag_only_kernel(const float* __restrict_
 // a9: perm = argsort(diag, descending), stable (ties keep ascending index), by rank counting:
 // rank(i) = #{j : d[j] > d[i]  or  (d[j] == d[i] and j < i)};  perm[rank(i)] = i, inv[i] = rank(i).
 // O(K^2) compares on K <= 32768 values staged through LDS in chunks: ~1 ms at K = 28672, exact and
-// deterministic (no sort network, no atomics).
+// deterministic (no sort network, no atomics).  NaN (a non-finite activation reached diag H) orders as
+// the largest value with the index tie-break, as torch.argsort(descending=True) places it, so perm
+// is a permutation for ANY input and the gathers that index with it stay in bounds.
 __global__ __launch_bounds__(256) void argsort_rank_kernel(const float* __restrict__ d, int K,
                                                            int32_t* __restrict__ perm, int32_t* __restrict__ inv) {
     __shared__ float chunk[1024];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const float di = (i < K) ? d[i] : 0.0f;
+    const bool nan_i = di != di;
     int rank = 0;
     for (int c0 = 0; c0 < K; c0 += 1024) {
         __syncthreads();
@@ -77,7 +80,10 @@ __global__ __launch_bounds__(256) void argsort_rank_kernel(const float* __restri
         const int lim = (K - c0 < 1024) ? K - c0 : 1024;
         for (int e = 0; e < lim; ++e) {
             const float dj = chunk[e];
-            rank += (dj > di) || (dj == di && (c0 + e) < i);
+            const bool nan_j = dj != dj;
+            const bool gt = nan_j ? !nan_i : (dj > di);
+            const bool eq = nan_j ? nan_i : (dj == di);
+            rank += gt || (eq && (c0 + e) < i);
         }
     }
     if (i < K) {

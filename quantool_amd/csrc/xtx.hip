@@ -2,43 +2,84 @@
 // through src/quantool/methods/llm_compressor/base.py:161).
 //
 // MFMA-bound (arithmetic intensity ~K flop/B).  X is [tokens][channels] bf16, so BOTH MFMA
-// operands are "k-strided" (the reduction index is the row index): X tiles are staged row-major
-// into LDS by LDS-DMA (global_load_lds, 16 B/lane) with the swizzle on the SOURCE address, and
-// read back with the hardware transposing read ds_read_b64_tr_b16.
+// operands are "k-strided" (the reduction index is the row index): X is staged row-major into
+// LDS by LDS-DMA (global_load_lds, 16 B/lane) with the swizzle on the SOURCE address, and read
+// back with the hardware transposing read ds_read_b64_tr_b16.
 //
-// Work decomposition: lower-triangular 256x256 output tiles x S token chunks.  Every workgroup
-// writes its fp32 partial tile to a slab; xtx_reduce_kernel sums the S slabs of a tile in fixed
-// order and adds them into G (deterministic; no atomics).
+// Loop structure.  Because the reduction index is the token index and X rows are
+// channel-contiguous, the natural staging unit is a slice of TOKENS, not of channels:
+//   unit  = 16 tokens x (256 A-panel + 256 B-panel channels) = 16 KiB = exactly one
+//           v_mfma_f32_32x32x16_bf16 k-step for the whole 256x256 tile;
+//   ring  = 8 units of LDS (128 KiB); unit u is consumed in phase u and its slot is re-filled
+//           with unit u+8; the LDS-DMA of unit u+6 is issued in phase u, so FIVE units (80 KiB per
+//           CU) are always in flight behind a COUNTED s_waitcnt vmcnt(10) -- never 0 in the loop;
+//   phase = { 12 transposing reads of unit u ; issue unit u+6 ; vmcnt(10) ; s_barrier ;
+//             lgkmcnt(0) ; 8 MFMAs ; s_barrier };
+//   waves 4-7 run the same program one barrier behind waves 0-3, so on every SIMD one wave's
+//   LDS reads / DMA issue run under its partner's 8 MFMAs (ping-pong), and a unit's slot is free
+//   two phases after it was read (hazard analysis at the kernel).
+//
+// Work decomposition: lower-triangular 256x256 output tiles.  Whole "rounds" of 256 tiles run one
+// workgroup per tile over ALL tokens and add their tile straight into G from the epilogue (no slab
+// round trip); the remaining tiles are split over token chunks into fp32 slabs that
+// xtx_reduce_kernel sums in fixed order (deterministic; no atomics).  Workgroups are mapped so that
+// the 32 resident on one XCD form a 4x8 block of tiles and all 256 of a round form a 16x16 block
+// walking the tokens together: a panel missed by one XCD's L2 is in the Infinity Cache for the rest.
 #include <stdlib.h>
 
 #include <map>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
 
+// round-1 kernel (xtx_v1.hip), kept for same-process A/B runs: QT_XTX_IMPL=0
+size_t qt_xtx_v1_workspace_bytes(int64_t n_tokens, int K);
+int qt_xtx_v1_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G, void* workspace,
+                         size_t workspace_bytes, qt_stream_t stream_);
+
 namespace {
 
-constexpr int BT = 256;                    // output tile edge (channels)
-constexpr int BKT = 64;                    // tokens per K-step
-constexpr int NTHREADS = 512;              // 8 waves: 2 (M) x 4 (N), 128x64 outputs per wave
-constexpr int OP_BYTES = BKT * BT * 2;     // one operand panel in LDS (32 KiB)
-constexpr int STAGE_BYTES = 2 * OP_BYTES;  // A + B; two stages = 128 KiB of LDS
+constexpr int BT = 256;                       // output tile edge (channels)
+constexpr int BKT = 64;                       // tokens per token tile (split / tail granularity)
+constexpr int UT = 16;                        // tokens per unit = one MFMA k-step
+constexpr int UNIT_BYTES = UT * 2 * BT * 2;   // A + B panels, 16 KiB
+constexpr int RING = 8;                       // units resident in LDS (128 KiB)
+constexpr int LEAD = 6;                       // unit u+LEAD is issued in phase u  (LEAD <= RING-2)
+constexpr int NTHREADS = 512;                 // 8 waves: 2 (M) x 4 (N), 128x64 outputs per wave
 constexpr int NUM_CU = 256;
 
 struct XtxParams {
     const __bf16* X;
-    const __bf16* tail;  // zero-padded [64, K] staging of the ragged last token tile (ld = K)
+    const __bf16* tail;  // zero-padded [64, ldx] staging of the ragged last token tile
     int64_t ldx;
     int K;
     int n_tt;       // token tiles (of 64) including the tail tile
     int has_tail;
-    int n_tiles;    // lower-triangular 256x256 tiles
-    int n_splits;   // S
-    float* slabs;   // [S][n_tiles][256*256]
-    const int* tile_tab;  // [n_tiles] (ti << 16) | tj, in L2-friendly super-tile order
-    int map_mode;         // workgroup -> (chunk, tile) mapping (see kernel)
-    int tiles_per_xcd;
+    const int* tile_tab;  // [n_tiles] (ti << 16) | tj in locality order (xtx_tile_order)
+    int n_direct;   // logical items [0, n_direct): one tile each over all tokens, added into G
+    int n_rem;      // tiles after those, each split over s2 token chunks -> slabs
+    int s2;
+    float* slabs;   // [s2][n_rem][256*256]
+    float* G;
+    int map_mode;   // 0: rounds of 256 with XCD-contiguous blocks of 32; 1: identity
 };
+
+// LDS-DMA from inline asm: hipcc does not track it, so it inserts no vmcnt drain in front of later
+// ds_reads or barriers.  Every completion is ordered by hand (counted vmcnt + s_barrier below).
+// saddr form: 64-bit scalar base + 32-bit per-lane byte offset; M0 = wave-uniform LDS destination.
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
 
 __device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
     // two transposing reads: tokens +0..3 and +4..7 (rows are 256 B apart -> +1024 B)
@@ -48,83 +89,93 @@ __device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
-    // Two DISTINCT LDS objects (not one array with two halves): hipcc then knows that the
-    // ds_reads of one stage cannot alias the in-flight LDS-DMA writes of the other and stops
-    // inserting s_waitcnt vmcnt(0) in front of every stage's first read (which serialised the
-    // prefetch of tile t+1 with the compute of tile t).
-    __shared__ __attribute__((aligned(16))) char stage0[STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char stage1[STAGE_BYTES];
+    // ONE LDS object: the ring.  Unit image: [4 channel groups: A-lo, A-hi, B-lo, B-hi][16 tokens][256 B].
+    __shared__ __attribute__((aligned(16))) char ring[RING * UNIT_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 2, wave_n = wave & 3;
+    const bool group_b = wave >= 4;  // wave-uniform
 
-    // XCD-aware remap (bijective form): workgroups that share an XCD get consecutive logical
-    // ids = consecutive entries of the tile table for one token chunk.  The table walks the
-    // lower triangle in 4x8 super-tiles, so the 32 workgroups resident on an XCD touch ~12
-    // distinct X panels per K-step instead of ~33: the rest are hits in that XCD's L2.
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    int chunk, tile;
-    if (p.map_mode == 2) {
-        // all 8 XCDs walk the token chunks together, each over its own contiguous slice of the
-        // tile table: a panel missed by one XCD's L2 is a MALL hit for the other seven
-        const int xcd = orig & 7, pos = orig >> 3;
-        chunk = pos / p.tiles_per_xcd;
-        tile = xcd * p.tiles_per_xcd + (pos - chunk * p.tiles_per_xcd);
-        if (tile >= p.n_tiles || chunk >= p.n_splits) return;
-    } else if (p.map_mode == 1) {
-        chunk = orig / p.n_tiles;
-        tile = orig - chunk * p.n_tiles;
-    } else {
-        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-        const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-        chunk = logical / p.n_tiles;
-        tile = logical - chunk * p.n_tiles;
-    }
-    const int tt_packed = p.tile_tab[tile];
-    const int ti = tt_packed >> 16, tj = tt_packed & 0xFFFF;
-    const bool diag = (ti == tj);
-
-    const int base_cnt = p.n_tt / p.n_splits, rem = p.n_tt % p.n_splits;
-    const int tt0 = chunk * base_cnt + (chunk < rem ? chunk : rem);
-    const int cnt = base_cnt + (chunk < rem ? 1 : 0);
-
-    // ---- staging geometry (per thread) ----
-    const int row_lo = tid >> 4;                        // 0..31
-    const int pch = tid & 15;                           // physical 16-B chunk in the 256-B row
-    const int lch = pch ^ ((row_lo & 3) << 2);          // logical chunk (source-side swizzle)
-    const int K = p.K;
-
-    auto stage = [&](char* sbase, int tt) {
-        const bool is_tail = p.has_tail && (tt == p.n_tt - 1);
-        const __bf16* src = is_tail ? p.tail : p.X + (size_t)tt * BKT * (size_t)p.ldx;
-        const size_t ld = is_tail ? (size_t)K : (size_t)p.ldx;
-        const int nops = diag ? 1 : 2;
-        for (int op = 0; op < nops; ++op) {
-            const int c0 = (op == 0 ? ti : tj) * BT;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row_lo + 32 * (r & 1);
-                int col = c0 + (r >> 1) * 128 + lch * 8;
-                col = col > K - 8 ? K - 8 : col;  // edge tiles: clamp (masked at the store)
-                const __bf16* g = src + (size_t)row * ld + col;
-                char* l = sbase + op * OP_BYTES + r * 8192 + wave * 1024;
-                __builtin_amdgcn_global_load_lds((const QT_GLOBAL void*)g, (QT_LDS void*)l, 16, 0, 0);
-            }
+    // ---- workgroup -> work item ------------------------------------------------------------
+    // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one; speed only, never
+    // correctness).  Within each round of 256 consecutive blocks, the 32 blocks of one XCD take 32
+    // consecutive logical items = one 4x8 block of tiles of the table.
+    int logical;
+    {
+        const int b = blockIdx.x, nwg = gridDim.x;
+        if (p.map_mode == 0) {
+            const int round = b >> 8, rb = b & 255;
+            const int m = min(256, nwg - (round << 8));
+            const int xcd = rb & 7, idx = rb >> 3, q8 = m >> 3, r8 = m & 7;
+            logical = (round << 8) + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        } else {
+            logical = b;
         }
+    }
+    int tile_idx, tt0, cnt, slab_idx = -1;
+    if (logical < p.n_direct) {
+        tile_idx = logical;
+        tt0 = 0;
+        cnt = p.n_tt;
+    } else {
+        const int l2 = logical - p.n_direct;
+        const int chunk = l2 / p.n_rem;
+        tile_idx = p.n_direct + (l2 - chunk * p.n_rem);
+        const int base_cnt = p.n_tt / p.s2, rem = p.n_tt % p.s2;
+        tt0 = chunk * base_cnt + (chunk < rem ? chunk : rem);
+        cnt = base_cnt + (chunk < rem ? 1 : 0);
+        slab_idx = l2;
+    }
+    const int tt_packed = p.tile_tab[tile_idx];
+    const int ti = tt_packed >> 16, tj = tt_packed & 0xFFFF;
+    const int nu = cnt * (BKT / UT);  // units of this item (a multiple of 4)
+    const int K = p.K;
+    const size_t ld2 = (size_t)p.ldx * 2;  // row pitch in bytes (the tail staging uses the same pitch)
+
+    // ---- staging geometry: two LDS-DMA instructions per thread per unit (A panel, B panel) ----
+    // wave w fills token rows 4*(w&3)..+3 of channel group (w>>2) (+2 for the B panel): 1 KiB,
+    // lane-linear; the XOR swizzle of the 16-B chunk index is applied to the SOURCE address.
+    const int rsub = lane >> 4;                       // token row inside the wave's 4-row piece
+    const int lch = (lane & 15) ^ (rsub << 2);        // logical 16-B chunk held at physical chunk lane&15
+    const int trow = 4 * (wave & 3) + rsub;           // token row inside the unit
+    int colA = ti * BT + (wave >> 2) * 128 + lch * 8;
+    int colB = tj * BT + (wave >> 2) * 128 + lch * 8;
+    colA = colA > K - 8 ? K - 8 : colA;               // edge tiles: clamp (masked at the store)
+    colB = colB > K - 8 ? K - 8 : colB;
+    const unsigned voffA = (unsigned)((size_t)trow * ld2 + (size_t)colA * 2);
+    const unsigned voffB = (unsigned)((size_t)trow * ld2 + (size_t)colB * 2);
+    const unsigned ring_lds = (unsigned)(size_t)(QT_LDS char*)ring;
+    const unsigned dst_wave = ring_lds + (wave >> 2) * 4096 + (wave & 3) * 1024;  // wave-uniform
+
+    auto unit_src = [&](int i) -> const char* {  // scalar: first token row of unit i
+        const int tt = tt0 + (i >> 2);
+        const char* base = (p.has_tail && tt == p.n_tt - 1) ? (const char*)p.tail
+                                                            : (const char*)p.X + (size_t)tt * BKT * ld2;
+        return base + (size_t)(i & 3) * UT * ld2;
+    };
+    auto issue = [&](int i, int slot) {
+        const char* src = unit_src(i);
+        const unsigned d = __builtin_amdgcn_readfirstlane(dst_wave + (unsigned)slot * UNIT_BYTES);
+        glds16(voffA, src, d);
+        glds16(voffB, src, d + 8192);
     };
 
-    // ---- fragment read geometry (per lane) ----
+    // ---- fragment read geometry (per lane), byte offsets inside a unit ----
     const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
-    const int low = 2 * (g & 1) + (pp >> 1);
-    const int rowpart = (8 * (g >> 1) + q) * 256 + 16 * low + 8 * (pp & 1);
+    const int rowpart = (8 * (g >> 1) + q) * 256 + 32 * (g & 1) + 8 * pp;
     int aoff[4], boff[2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) aoff[mi] = wave_m * 16384 + rowpart + 64 * (mi ^ q);
+    for (int mi = 0; mi < 4; ++mi) aoff[mi] = wave_m * 4096 + rowpart + 64 * (mi ^ q);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
-        boff[ni] = (wave_n >> 1) * 16384 + rowpart + 64 * ((((wave_n & 1) << 1) + ni) ^ q);
+        boff[ni] = (2 + (wave_n >> 1)) * 4096 + rowpart + 64 * ((((wave_n & 1) << 1) + ni) ^ q);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -134,73 +185,128 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    // Software-pipelined fragment reads: the 12 transposing reads of k-step ks+1 are issued
-    // BEFORE the 8 MFMAs of k-step ks (256 MFMA cycles cover the LDS latency) and waited for with
-    // a counted lgkmcnt after them; sched_barrier pins that order against hipcc's scheduler.
-    auto compute = [&](const char* abase) {
-        const char* bbase = diag ? abase : abase + OP_BYTES;
-        bf16x8 a[2][4], b[2][2];
+    // ---- the pipeline --------------------------------------------------------------------------
+    // Intervals between consecutive workgroup barriers are numbered; waves 0-3 (group A) run
+    // LOAD(u) in interval 2u and MATH(u) in 2u+1, waves 4-7 (group B) one interval later.
+    //   RAW: unit u is read in intervals 2u (A) / 2u+1 (B).  Every wave waits for its own DMA of
+    //        unit u (counted vmcnt) in LOAD(u-1), i.e. in intervals 2u-2 / 2u-1, and the barrier
+    //        that ends interval 2u-1 follows both: "read one phase after the wait that retires it".
+    //   WAR: unit u's reads retire at the lgkmcnt(0) in MATH(u): intervals 2u+1 (A) / 2u+2 (B).
+    //        Its slot is re-filled with unit u+8, issued in LOAD(u+2): intervals 2u+4 / 2u+5,
+    //        after the barriers that end 2u+2 and 2u+3.
+    bf16x8 fa[4], fb[2];
+    auto load_part = [&](auto slot_c, auto steady_c, int u) {
+        constexpr int S = decltype(slot_c)::value;
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const char* base = ring + S * UNIT_BYTES;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a[0][mi] = tr_load8(abase + aoff[mi]);
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = tr_load8(base + aoff[mi]);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) b[0][ni] = tr_load8(bbase + boff[ni]);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) a[nxt][mi] = tr_load8(abase + aoff[mi] + (ks + 1) * 4096);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) b[nxt][ni] = tr_load8(bbase + boff[ni] + (ks + 1) * 4096);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int ni = 0; ni < 2; ++ni) fb[ni] = tr_load8(base + boff[ni]);
+        if (STEADY || u + LEAD < nu) {
+            issue(u + LEAD, (S + LEAD) & (RING - 1));
+            wait_vmcnt<2 * (LEAD - 1)>();  // everything up to unit u+1 has landed; 5 units stay in flight
+        } else {
+            // drain: no further issue; allow exactly the units after u+1 to stay in flight
+            const int later = nu - u - 2;
+            if (later >= 4) wait_vmcnt<8>();
+            else if (later == 3) wait_vmcnt<6>();
+            else if (later == 2) wait_vmcnt<4>();
+            else if (later == 1) wait_vmcnt<2>();
+            else wait_vmcnt<0>();
         }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto math_part = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase = [&](auto slot_c, auto steady_c, int u) {
+        load_part(slot_c, steady_c, u);
+        math_part();
+    };
+    auto body8 = [&](auto steady_c, int u) {
+        phase(std::integral_constant<int, 0>{}, steady_c, u);
+        phase(std::integral_constant<int, 1>{}, steady_c, u + 1);
+        phase(std::integral_constant<int, 2>{}, steady_c, u + 2);
+        phase(std::integral_constant<int, 3>{}, steady_c, u + 3);
+        phase(std::integral_constant<int, 4>{}, steady_c, u + 4);
+        phase(std::integral_constant<int, 5>{}, steady_c, u + 5);
+        phase(std::integral_constant<int, 6>{}, steady_c, u + 6);
+        phase(std::integral_constant<int, 7>{}, steady_c, u + 7);
     };
 
-    if (cnt > 0) {
-        stage(stage0, tt0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int t = 0;
-        for (; t + 1 < cnt; t += 2) {
-            stage(stage1, tt0 + t + 1);
-            compute(stage0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + 2 < cnt) stage(stage0, tt0 + t + 2);
-            compute(stage1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+    if (nu > 0) {
+        // prologue: units 0..LEAD-1 in flight, unit 0 landed
+#pragma unroll
+        for (int i = 0; i < LEAD; ++i)
+            if (i < nu) issue(i, i);
+        if (nu >= LEAD) wait_vmcnt<2 * (LEAD - 1)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (group_b) __builtin_amdgcn_s_barrier();  // stagger: group B runs one interval behind
+        __builtin_amdgcn_sched_barrier(0);
+
+        int u = 0;
+        for (; u + 8 + LEAD <= nu; u += 8) body8(std::true_type{}, u);
+        for (; u + 8 <= nu; u += 8) body8(std::false_type{}, u);
+        if (u < nu) {  // nu is a multiple of 4: one half body left
+            phase(std::integral_constant<int, 0>{}, std::false_type{}, u);
+            phase(std::integral_constant<int, 1>{}, std::false_type{}, u + 1);
+            phase(std::integral_constant<int, 2>{}, std::false_type{}, u + 2);
+            phase(std::integral_constant<int, 3>{}, std::false_type{}, u + 3);
         }
-        if (t < cnt) compute(stage0);
+        if (!group_b) __builtin_amdgcn_s_barrier();  // pairs with group B's last barrier
+        wait_vmcnt<0>();
     }
 
-    // ---- epilogue: fp32 partial tile -> slab (row-major 256x256) ----
-    float* slab = p.slabs + ((size_t)chunk * p.n_tiles + tile) * (size_t)(BT * BT);
+    // ---- epilogue ----------------------------------------------------------------------------
     const int jl = lane & 31, ih = 4 * (lane >> 5);
+    if (slab_idx < 0) {
+        // the only workgroup of this tile in this launch: G += acc (launches on a stream are ordered)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni) {
+                const int gj = tj * BT + wave_n * 64 + ni * 32 + jl;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i_loc = wave_m * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + ih;
-                const int j_loc = wave_n * 64 + ni * 32 + jl;
-                slab[i_loc * BT + j_loc] = acc[mi][ni][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = ti * BT + wave_m * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + ih;
+                    if (gi < K && gj < K) {
+                        float* dst = p.G + (size_t)gi * K + gj;
+                        *dst = *dst + acc[mi][ni][r];
+                    }
+                }
             }
+    } else {
+        float* slab = p.slabs + (size_t)slab_idx * (size_t)(BT * BT);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i_loc = wave_m * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + ih;
+                    const int j_loc = wave_n * 64 + ni * 32 + jl;
+                    slab[i_loc * BT + j_loc] = acc[mi][ni][r];
+                }
+    }
 }
 
-// G[tile] += sum_s slab[s][tile]  (ascending s; one float4 per thread per step)
-__global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ slabs, int n_tiles,
-                                                         int n_splits, float* __restrict__ G, int K,
+// G[tile] += sum_s slab[s][tile]  (ascending s; one float4 per thread per step) for the split tiles
+__global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ slabs, int n_rem, int n_splits,
+                                                         float* __restrict__ G, int K,
                                                          const int* __restrict__ tile_tab) {
     const int tile = blockIdx.x;
     const int tt_packed = tile_tab[tile];
@@ -214,7 +320,7 @@ __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict
         if (gi >= K || gj >= K) continue;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int sp = 0; sp < n_splits; ++sp) {
-            const f32x4 v = *(const f32x4*)(slabs + ((size_t)sp * n_tiles + tile) * tile_elems +
+            const f32x4 v = *(const f32x4*)(slabs + ((size_t)sp * n_rem + tile) * tile_elems +
                                             (size_t)i_loc * BT + j_loc);
             s += v;
         }
@@ -230,17 +336,22 @@ __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict
 }
 
 struct XtxPlan {
-    int n_tiles, n_tt, has_tail, n_splits;
+    int n_tiles, n_tt, has_tail;
+    int n_direct, n_rem, s2;
     size_t slab_bytes, tail_bytes, tab_bytes;
 };
 
-// lower-triangular tiles in 4 (rows) x 8 (cols) super-tile order
+// Lower-triangular tiles in locality order: bands of 16 tile rows, 16x16 macro blocks along a
+// band, 4 (rows) x 8 (cols) super-tiles inside a macro block, row-major inside a super-tile.  32
+// consecutive entries = one super-tile (12 distinct panels), 256 = one macro block (32 panels).
 void xtx_tile_order(int nt, std::vector<int>& tab) {
     tab.clear();
-    for (int bi = 0; bi < nt; bi += 4)
-        for (int bj = 0; bj <= bi + 3 && bj < nt; bj += 8)
-            for (int ti = bi; ti < bi + 4 && ti < nt; ++ti)
-                for (int tj = bj; tj < bj + 8 && tj <= ti; ++tj) tab.push_back((ti << 16) | tj);
+    for (int bi = 0; bi < nt; bi += 16)
+        for (int bj = 0; bj <= bi + 15 && bj < nt; bj += 16)
+            for (int si = bi; si < bi + 16 && si < nt; si += 4)
+                for (int sj = bj; sj < bj + 16 && sj < nt; sj += 8)
+                    for (int ti = si; ti < si + 4 && ti < nt; ++ti)
+                        for (int tj = sj; tj < sj + 8 && tj <= ti; ++tj) tab.push_back((ti << 16) | tj);
 }
 
 XtxPlan xtx_plan(int64_t n_tokens, int K) {
@@ -249,38 +360,74 @@ XtxPlan xtx_plan(int64_t n_tokens, int K) {
     pl.n_tiles = nt * (nt + 1) / 2;
     pl.n_tt = (int)((n_tokens + BKT - 1) / BKT);
     pl.has_tail = (n_tokens % BKT) != 0;
-    // choose the token split S that best fills 256 CUs (1 workgroup per CU) in whole rounds
+    // whole rounds of 256 tiles: one workgroup per tile over all tokens.  The leftover tiles are
+    // split over S token chunks so that they, too, fill whole rounds of the 256 CUs.
+    const int n_full = pl.n_tiles / NUM_CU * NUM_CU;
+    const int rem = pl.n_tiles - n_full;
     int best = 1;
-    double best_eff = -1.0;
-    const size_t slab_cap = (size_t)3 << 30;
-    for (int S = 1; S <= 64 && S <= (pl.n_tt > 0 ? pl.n_tt : 1); ++S) {
-        if (S > 1 && pl.n_tt / S < 4) break;
-        if ((size_t)S * pl.n_tiles * BT * BT * 4 > slab_cap) break;
-        const long wgs = (long)pl.n_tiles * S;
-        const long rounds = (wgs + NUM_CU - 1) / NUM_CU;
-        const double eff = (double)wgs / (double)(rounds * NUM_CU);
-        if (eff > best_eff + 0.02) {
-            best_eff = eff;
-            best = S;
+    if (rem > 0) {
+        const size_t slab_cap = (size_t)1 << 30;
+        double best_cost = 1.0;  // S = 1: one round at full length
+        for (int S = 2; S <= 64; ++S) {
+            if (pl.n_tt / S < 4) break;
+            if ((size_t)S * rem * BT * BT * 4 > slab_cap) break;
+            const long wgs = (long)rem * S;
+            const double cost = (double)((wgs + NUM_CU - 1) / NUM_CU) / S;  // rounds x (1/S of a full item)
+            if (cost < best_cost * 0.97) {
+                best_cost = cost;
+                best = S;
+            }
         }
     }
-    pl.n_splits = best;
-    pl.slab_bytes = (size_t)pl.n_splits * pl.n_tiles * BT * BT * 4;
+    pl.s2 = best;
+    if (pl.s2 == 1) {
+        pl.n_direct = pl.n_tiles;
+        pl.n_rem = 0;
+    } else {
+        pl.n_direct = n_full;
+        pl.n_rem = rem;
+    }
+    pl.slab_bytes = (size_t)pl.s2 * pl.n_rem * BT * BT * 4;
     pl.tail_bytes = pl.has_tail ? qt_align_up((size_t)BKT * K * 2, 256) : 0;
     pl.tab_bytes = qt_align_up((size_t)pl.n_tiles * 4, 256);
     return pl;
+}
+
+// Tile tables live in pinned host memory (one per K, for the life of the process), so the per-call
+// hipMemcpyAsync into the caller's workspace is a real asynchronous copy, not a staged one.
+const int* xtx_host_table(int K, int n_tiles) {
+    static std::mutex m;
+    static std::map<int, int*> tabs;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = tabs.find(K);
+    if (it != tabs.end()) return it->second;
+    std::vector<int> v;
+    xtx_tile_order((K + BT - 1) / BT, v);
+    if ((int)v.size() != n_tiles) return nullptr;
+    int* pinned = nullptr;
+    if (hipHostMalloc((void**)&pinned, v.size() * sizeof(int), hipHostMallocDefault) != hipSuccess) return nullptr;
+    for (size_t i = 0; i < v.size(); ++i) pinned[i] = v[i];
+    tabs[K] = pinned;
+    return pinned;
+}
+
+int xtx_impl() {
+    const char* e = getenv("QT_XTX_IMPL");
+    return e ? atoi(e) : 1;
 }
 
 }  // namespace
 
 extern "C" size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K) {
     if (n_tokens <= 0 || K <= 0) return 0;
+    if (xtx_impl() == 0) return qt_xtx_v1_workspace_bytes(n_tokens, K);
     XtxPlan pl = xtx_plan(n_tokens, K);
     return pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
 }
 
 extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G,
                                  void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+    if (xtx_impl() == 0) return qt_xtx_v1_accumulate(X, n_tokens, K, ldx, G, workspace, workspace_bytes, stream_);
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(K > 0 && K % 8 == 0, "qt_xtx_accumulate: K=%d must be a positive multiple of 8", K);
     QT_CHECK_ARG(ldx >= K && ldx % 8 == 0, "qt_xtx_accumulate: ldx=%lld must be >= K and a multiple of 8", (long long)ldx);
@@ -288,6 +435,8 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     if (n_tokens == 0) return QT_OK;
     QT_CHECK_ARG(X && G, "qt_xtx_accumulate: null pointer");
     QT_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)G & 15) == 0, "qt_xtx_accumulate: X and G must be 16-byte aligned");
+    // per-lane source offsets are 32-bit: 16 token rows of one unit must span < 4 GiB
+    QT_CHECK_ARG((uint64_t)ldx * 2 * UT + (uint64_t)K * 2 < ((uint64_t)1 << 32), "qt_xtx_accumulate: ldx too large");
     XtxPlan pl = xtx_plan(n_tokens, K);
     const size_t need = pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
     if (workspace_bytes < need || !workspace) {
@@ -298,23 +447,31 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     float* slabs = (float*)ws;
     __bf16* tail = pl.has_tail ? (__bf16*)(ws + pl.slab_bytes) : nullptr;
     int* tile_tab = (int*)(ws + pl.slab_bytes + pl.tail_bytes);
+    const int* host_tab = xtx_host_table(K, pl.n_tiles);
+    if (!host_tab) {
+        qt_set_error("qt_xtx_accumulate: could not build the tile table for K=%d", K);
+        return QT_ERR_HIP;
+    }
+    QT_HIP(hipMemcpyAsync(tile_tab, host_tab, (size_t)pl.n_tiles * 4, hipMemcpyHostToDevice, stream));
+    // The ragged last token tile is staged zero-padded with pitch K.  The kernel reads every unit
+    // with ONE pitch (its per-lane offsets are loop constants), so the staging can stand in for the
+    // last tile only when ldx == K; otherwise the call becomes two launches (below).
+    XtxParams p;
+    p.X = (const __bf16*)X;
+    p.tail = tail;
+    p.ldx = ldx;
+    p.K = K;
+    p.n_tt = pl.n_tt;
+    p.has_tail = pl.has_tail;
+    p.tile_tab = tile_tab;
+    p.n_direct = pl.n_direct;
+    p.n_rem = pl.n_rem;
+    p.s2 = pl.s2;
+    p.slabs = slabs;
+    p.G = G;
     {
-        // host copy kept alive for the life of the process (the async copy reads it); std::map
-        // nodes do not move, so the reference stays valid after the lock is dropped
-        static std::mutex tabs_mutex;
-        static std::map<int, std::vector<int>> tabs;
-        std::vector<int>* tab_ptr;
-        {
-            std::lock_guard<std::mutex> lock(tabs_mutex);
-            tab_ptr = &tabs[K];
-            if (tab_ptr->empty()) xtx_tile_order((K + BT - 1) / BT, *tab_ptr);
-        }
-        std::vector<int>& tab = *tab_ptr;
-        if ((int)tab.size() != pl.n_tiles) {
-            qt_set_error("qt_xtx_accumulate: internal tile table size mismatch");
-            return QT_ERR_INVALID;
-        }
-        QT_HIP(hipMemcpyAsync(tile_tab, tab.data(), (size_t)pl.n_tiles * 4, hipMemcpyHostToDevice, stream));
+        const char* e = getenv("QT_XTX_MAP");
+        p.map_mode = e ? atoi(e) : 0;
     }
     if (pl.has_tail) {
         const int64_t full = n_tokens / BKT * BKT;
@@ -323,30 +480,53 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
         QT_HIP(hipMemcpy2DAsync(tail, (size_t)K * 2, (const char*)X + (size_t)full * ldx * 2, (size_t)ldx * 2,
                                 (size_t)K * 2, (size_t)tail_rows, hipMemcpyDeviceToDevice, stream));
     }
-    XtxParams p;
-    p.X = (const __bf16*)X;
-    p.tail = tail;
-    p.ldx = ldx;
-    p.K = K;
-    p.n_tt = pl.n_tt;
-    p.has_tail = pl.has_tail;
-    p.n_tiles = pl.n_tiles;
-    p.n_splits = pl.n_splits;
-    p.slabs = slabs;
-    p.tile_tab = tile_tab;
-    static const int map_mode = [] {
-        const char* e = getenv("QT_XTX_MAP");
-        return e ? atoi(e) : 0;
-    }();
-    p.map_mode = map_mode;
-    p.tiles_per_xcd = (pl.n_tiles + 7) / 8;
-    const int grid = (map_mode == 2) ? 8 * p.tiles_per_xcd * pl.n_splits : pl.n_tiles * pl.n_splits;
-    qt_prof_mark(QT_PROF_XTX, stream);
-    hipLaunchKernelGGL(xtx_kernel, dim3(grid), dim3(NTHREADS), 0, stream, p);
-    qt_prof_mark(QT_PROF_XTX, stream);
-    QT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(xtx_reduce_kernel, dim3(pl.n_tiles, 16), dim3(256), 0, stream, slabs, pl.n_tiles,
-                       pl.n_splits, G, K, (const int*)tile_tab);
-    QT_LAUNCH_CHECK();
-    return QT_OK;
+    auto launch = [&](const XtxParams& q, const XtxPlan& ql) -> int {
+        const int grid = ql.n_direct + ql.n_rem * ql.s2;
+        qt_prof_mark(QT_PROF_XTX, stream);
+        hipLaunchKernelGGL(xtx_kernel, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        qt_prof_mark(QT_PROF_XTX, stream);
+        QT_LAUNCH_CHECK();
+        if (ql.n_rem > 0) {
+            hipLaunchKernelGGL(xtx_reduce_kernel, dim3(ql.n_rem, 16), dim3(256), 0, stream, q.slabs, ql.n_rem, ql.s2,
+                               q.G, q.K, q.tile_tab + ql.n_direct);
+            QT_LAUNCH_CHECK();
+        }
+        return QT_OK;
+    };
+    if (pl.has_tail && ldx != K) {
+        // two launches: the full token tiles with pitch ldx, then the 64 staged rows with pitch K
+        const int64_t full = n_tokens / BKT * BKT;
+        if (full > 0) {
+            XtxPlan pf = xtx_plan(full, K);
+            // the split plan of the shorter call must fit the slab area sized for the whole call
+            if (pf.slab_bytes > pl.slab_bytes) {
+                pf.s2 = 1;
+                pf.n_direct = pf.n_tiles;
+                pf.n_rem = 0;
+                pf.slab_bytes = 0;
+            }
+            XtxParams pfp = p;
+            pfp.n_tt = pf.n_tt;
+            pfp.has_tail = 0;
+            pfp.n_direct = pf.n_direct;
+            pfp.n_rem = pf.n_rem;
+            pfp.s2 = pf.s2;
+            const int rc = launch(pfp, pf);
+            if (rc != QT_OK) return rc;
+        }
+        XtxPlan pt = xtx_plan(BKT, K);
+        pt.s2 = 1;
+        pt.n_direct = pt.n_tiles;
+        pt.n_rem = 0;
+        XtxParams ptp = p;
+        ptp.X = tail;
+        ptp.ldx = K;
+        ptp.n_tt = 1;
+        ptp.has_tail = 0;
+        ptp.n_direct = pt.n_direct;
+        ptp.n_rem = 0;
+        ptp.s2 = 1;
+        return launch(ptp, pt);
+    }
+    return launch(p, pl);
 }

@@ -23,24 +23,70 @@ class HessianAccumulator:
     (a7); ``(2/n) * G`` is the same matrix and the factor is applied in ``hessian_prepare``.
     Linears that read the same input (q/k/v, gate/up) share one accumulator: their upstream
     Hessians are byte-identical, so one X^T X pass and one factorisation serve them all.
+
+    The reference's calling pattern is one sample per batch (``base.py:161``; SURVEY A.1: batch
+    size 1, T <= 384 tokens).  A Gram launch that short cannot fill the chip and would re-read and
+    re-write the whole K x K fp32 ``G`` per sample, so ``add`` appends small batches to a device
+    token buffer ``[stage_tokens, K]`` and launches ``qt_xtx_accumulate`` once per full buffer
+    (and on ``flush``, which every reader of ``G`` goes through).  Batches of ``direct_tokens`` or
+    more skip the buffer.
     """
 
-    def __init__(self, K: int, device):
+    STAGE_BYTES = 1 << 30      # default token buffer: 1 GiB worth of rows, 4096..65536 tokens
+    DIRECT_TOKENS = 16384      # a batch this long is worth its own launch
+
+    def __init__(self, K: int, device, stage_tokens: Optional[int] = None, dtype=torch.bfloat16):
         self.K = K
-        self.G = torch.zeros((K, K), dtype=torch.float32, device=device)
+        self.dtype = dtype
+        self._G = torch.zeros((K, K), dtype=torch.float32, device=device)
         self.n = 0
+        if stage_tokens is None:
+            stage_tokens = max(4096, min(65536, self.STAGE_BYTES // (2 * K)))
+        self.stage_tokens = int(stage_tokens) // 64 * 64
+        self._stage: Optional[torch.Tensor] = None
+        self._fill = 0
+
+    @property
+    def G(self) -> torch.Tensor:
+        """The Gram sum with every staged token folded in."""
+        self.flush()
+        return self._G
+
+    @G.setter
+    def G(self, value: torch.Tensor) -> None:
+        self._G = value
 
     def add(self, X: torch.Tensor, num_samples: Optional[int] = None) -> None:
-        """X: [B, T, K] or [T, K] in bf16.  ``num_samples`` defaults to B (upstream's num_added)."""
-        if X.dtype != torch.bfloat16:
-            X = X.to(torch.bfloat16)
+        """X: [B, T, K] or [T, K].  ``num_samples`` defaults to B (upstream's num_added)."""
         if num_samples is None:
             num_samples = X.shape[0] if X.dim() == 3 else 1
-        ops.xtx_accumulate(X, self.G)
+        X2 = X.reshape(-1, self.K)
+        t = X2.shape[0]
         self.n += int(num_samples)
+        if t == 0:
+            return
+        if self.stage_tokens <= 0 or t >= min(self.DIRECT_TOKENS, self.stage_tokens):
+            ops.xtx_accumulate(X2 if X2.dtype == self.dtype else X2.to(self.dtype), self._G)
+            return
+        if self._stage is None:
+            self._stage = torch.empty((self.stage_tokens, self.K), dtype=self.dtype, device=self._G.device)
+        if self._fill + t > self.stage_tokens:
+            self.flush()
+        self._stage[self._fill:self._fill + t].copy_(X2)     # also the dtype conversion, if any
+        self._fill += t
+
+    def flush(self) -> None:
+        if self._fill:
+            ops.xtx_accumulate(self._stage[:self._fill], self._G)
+            self._fill = 0
+
+    def release_stage(self) -> None:
+        self.flush()
+        self._stage = None
 
     def reset(self) -> None:
-        self.G.zero_()
+        self._fill = 0
+        self._G.zero_()
         self.n = 0
 
 

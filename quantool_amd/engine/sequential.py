@@ -51,6 +51,22 @@ def build_batches(dataset, tokenizer, num_samples: int, max_seq_length: int, shu
             if len(out) >= num_samples:
                 break
         return out
+    if isinstance(dataset, (str, Path)):
+        # upstream's oneshot(dataset="name") downloads the named dataset; this backend never fetches.
+        # A local .json / .jsonl file of rows is read; anything else is refused instead of being
+        # iterated character by character.
+        path = Path(dataset)
+        if path.is_file() and path.suffix in (".json", ".jsonl"):
+            import json
+
+            text = path.read_text(encoding="utf-8")
+            dataset = json.loads(text) if path.suffix == ".json" else [json.loads(l) for l in text.splitlines() if l.strip()]
+        else:
+            raise ValueError(
+                f"dataset={str(dataset)!r}: a dataset id cannot be resolved here (no hub access in this backend). "
+                "Pass a datasets.Dataset, a list of rows, a local .json/.jsonl file, or calibration_dataloader.")
+    if dataset is None:
+        raise ValueError("no calibration data: pass dataset=, dataset_path= or calibration_dataloader=")
     if hasattr(dataset, "keys") and not hasattr(dataset, "column_names") and not isinstance(dataset, dict):
         dataset = dataset[list(dataset.keys())[0]]
     rows = list(dataset)
@@ -66,7 +82,14 @@ def build_batches(dataset, tokenizer, num_samples: int, max_seq_length: int, shu
         elif isinstance(row, dict) and "input_ids" in row:
             ids = torch.as_tensor(row["input_ids"])
         else:
-            text = row[text_column] if isinstance(row, dict) else row
+            if isinstance(row, dict) and text_column in row:
+                text = row[text_column]
+            elif isinstance(row, str):
+                text = row
+            else:
+                have = sorted(row) if isinstance(row, dict) else type(row).__name__
+                raise ValueError(f"calibration row {i} is neither a tensor, a dict with 'input_ids' or "
+                                 f"{text_column!r}, nor a string (got {have})")
             if tokenizer is None:
                 raise ValueError("a tokenizer is required to calibrate on text rows")
             ids = torch.as_tensor(tokenizer(text, truncation=True, max_length=max_seq_length,

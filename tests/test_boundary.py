@@ -283,3 +283,31 @@ def test_quantization_config_carries_the_activation_block(scheme, acts):
         a = group["input_activations"]
         assert (a["num_bits"], a["strategy"], a["dynamic"], a["symmetric"]) == acts
     assert ql.quantization_config()["format"] == mod.resolved_scheme.format
+
+
+def test_build_batches_refuses_dataset_ids_and_malformed_rows(tmp_path):
+    """Upstream's oneshot(dataset="name") loads the named dataset (the reference CLI passes the id,
+    cli.py:334); this backend never fetches, so a dataset id must fail loudly instead of being
+    iterated character by character, and rows the driver cannot tokenise must be named."""
+    import json
+
+    import torch
+
+    from quantool_amd.engine.sequential import build_batches
+
+    class Tok:
+        def __call__(self, text, **kw):
+            return {"input_ids": [ord(c) % 50 for c in text][: kw.get("max_length", 8)]}
+
+    with pytest.raises(ValueError, match="dataset id cannot be resolved"):
+        build_batches("HuggingFaceH4/ultrachat_200k", Tok(), 4, 8, False, 0, "text")
+    with pytest.raises(ValueError, match="neither a tensor"):
+        build_batches([{"prompt": "x"}], Tok(), 4, 8, False, 0, "text")
+    with pytest.raises(ValueError, match="no calibration data"):
+        build_batches(None, Tok(), 4, 8, False, 0, "text")
+    f = tmp_path / "rows.jsonl"
+    f.write_text("\n".join(json.dumps({"text": t}) for t in ("hello world", "second row")))
+    got = build_batches(str(f), Tok(), 4, 8, False, 0, "text")
+    assert len(got) == 2 and got[0]["input_ids"].shape == (1, 8) and got[0]["input_ids"].dtype == torch.long
+    got = build_batches(["abc", torch.arange(5), {"input_ids": [1, 2, 3]}], Tok(), 8, 4, False, 0, "text")
+    assert [b["input_ids"].shape[1] for b in got] == [3, 4, 3]

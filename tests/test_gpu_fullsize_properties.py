@@ -1,6 +1,8 @@
 """BASELINE.json's full sizes (Llama-3-8B shapes, 196 608 calibration tokens) through
-size-independent properties -- the oracle cannot run these sizes in seconds, so each test checks
-an identity the algorithm must satisfy at any size."""
+size-independent properties: identities the algorithm must satisfy at any size, checked where an
+fp64 Gram matrix over all 196 608 tokens or a K^3 host factorisation would take minutes.  The
+oracle comparisons at the real in_features (4096 x 4096 in full, a row slice at K = 14336) are in
+``test_gpu_fullsize_oracle.py``."""
 import numpy as np
 import pytest
 import torch

@@ -54,6 +54,57 @@ def test_xtx_is_deterministic_and_handles_3d_input(ops, dev):
     assert torch.equal(torch.tril(G1), torch.tril(G2))
 
 
+@pytest.mark.parametrize("n_tokens,K,pad", [(4096, 2816, 0), (1000 + 13, 768, 64), (2048, 4352, 0)])
+def test_xtx_split_tiles_strided_and_ragged(ops, oracle, dev, n_tokens, K, pad):
+    """Paths the small cases do not reach: more tiles than one round can take plus a remainder that is
+    split over token chunks into slabs (K = 4352: 153 tiles; K = 2816: 66 tiles x S chunks), a row
+    pitch larger than K, and a ragged token tail together with that pitch (two launches)."""
+    xb = synth_activations(n_tokens, K, seed=n_tokens + K)
+    X = bits_to_bf16_tensor(xb, dev)
+    if pad:
+        Xw = torch.zeros((n_tokens, K + pad), dtype=torch.bfloat16, device=dev)
+        Xw[:, :K] = X
+        X = Xw[:, :K]
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    ops.xtx_accumulate(X, G)
+    torch.cuda.synchronize()
+    Gt = oracle.gram_f64(xb)
+    d = np.sqrt(np.diag(Gt))
+    got = np.tril(G.cpu().numpy().astype(np.float64))
+    assert np.all(np.abs(got - 2 * np.tril(Gt)) <= 2e-5 * np.tril(np.outer(d, d)) + 1e-30)
+
+
+def test_per_sample_staging_matches_single_launch(ops, oracle, dev):
+    """The plugin path's calling pattern (reference base.py:161: one sample per batch) goes through the
+    accumulator's device token buffer; the result must be the Gram sum a single launch gives (the
+    fp32 partial sums are grouped differently: 1e-5 on G, north_star's bar) and n the sample count."""
+    from quantool_amd.engine.gptq_linear import HessianAccumulator
+
+    S, T, K = 40, 96, 520
+    xb = synth_activations(S * T, K, seed=5)
+    X = bits_to_bf16_tensor(xb, dev).reshape(S, T, K)
+    one = HessianAccumulator(K, dev, stage_tokens=0)
+    one.add(X)
+    staged = HessianAccumulator(K, dev, stage_tokens=1024)       # forces several flushes
+    for i in range(S):
+        staged.add(X[i:i + 1])
+    assert staged._fill > 0                                        # something is still staged ...
+    Gs = staged.G                                                  # ... and reading G folds it in
+    assert staged._fill == 0 and staged.n == one.n == S
+    Gt = oracle.gram_f64(xb)
+    d = np.sqrt(np.diag(Gt))
+    for G in (one.G, Gs):
+        got = np.tril(G.cpu().numpy().astype(np.float64))
+        assert np.all(np.abs(got - np.tril(Gt)) <= 1e-5 * np.tril(np.outer(d, d)) + 1e-30)
+    # a batch at least DIRECT_TOKENS long skips the buffer; staged rows still come first or later, never lost
+    big = HessianAccumulator(K, dev, stage_tokens=512)
+    big.add(X[:2].reshape(-1, K), num_samples=2)
+    big.add(X[2:].reshape(-1, K), num_samples=S - 2)               # 3648 rows >= stage_tokens -> direct launch
+    got = np.tril(big.G.cpu().numpy().astype(np.float64))
+    assert np.all(np.abs(got - np.tril(Gt)) <= 1e-5 * np.tril(np.outer(d, d)) + 1e-30)
+
+
 def test_xtx_rejects_bad_shapes(ops, dev):
     from quantool_amd.hip._lib import HipBackendError
 

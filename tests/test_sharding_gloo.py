@@ -48,10 +48,16 @@ def _worker(rank, world, port, q):
             local[f"{units[i]}.weight_scale"] = torch.randn(8, 2, generator=g).to(torch.bfloat16)
         # partitioning B: token-split Gram partials summed across ranks
         g = torch.Generator().manual_seed(7)
-        X = torch.randn(64, 16, generator=g, dtype=torch.float64)
-        part = X[rank::world].t() @ X[rank::world]
+        X = torch.randn(64, 300, generator=g, dtype=torch.float64)      # K = 300: two 256-row bands
+        mine_only = X[rank::world].t() @ X[rank::world]
+        part = mine_only.clone()
         n_tot = allreduce_gram(part, 32 // world + (1 if rank == 0 else 0))
-        assert n_tot == 33 and torch.allclose(part, X.t() @ X)
+        full = X.t() @ X
+        assert n_tot == 33
+        # the bands of the lower triangle (what the Gram kernel writes) are summed over the ranks ...
+        assert torch.allclose(part[:256, :256], full[:256, :256]) and torch.allclose(part[256:], full[256:])
+        # ... and nothing else travels: the block above the diagonal tiles keeps the local partial
+        assert torch.equal(part[:256, 256:], mine_only[:256, 256:])
         merged = gather_state_dict(local, dst=0)
         if rank == 0:
             ok = len(merged) == 10
