@@ -45,7 +45,6 @@ constexpr int BKT = 64;                       // tokens per token tile (split / 
 constexpr int UT = 16;                        // tokens per unit = one MFMA k-step
 constexpr int UNIT_BYTES = UT * 2 * BT * 2;   // A + B panels, 16 KiB
 constexpr int RING = 8;                       // units resident in LDS (128 KiB)
-constexpr int LEAD = 6;                       // unit u+LEAD is issued in phase u  (LEAD <= RING-2)
 constexpr int NTHREADS = 512;                 // 8 waves: 2 (M) x 4 (N), 128x64 outputs per wave
 constexpr int NUM_CU = 256;
 
@@ -81,6 +80,32 @@ __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigne
         : "memory");
 }
 
+// Both LDS-DMA instructions of one unit (A panel, B panel) in one statement.  M0 is written in the
+// statement that reads it and is not restored: nothing else in this kernel uses M0 (LDS instructions
+// need none on gfx9+), which the build checks by grepping the kernel's ISA for m0 outside these blocks.
+__device__ __forceinline__ void glds16_pair(unsigned voffA, unsigned voffB, const void* sbase, unsigned ldsA,
+                                            unsigned ldsB) {
+    asm volatile(
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %2\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2"
+        :
+        : "v"(voffA), "v"(voffB), "s"(sbase), "s"(ldsA), "s"(ldsB)
+        : "memory");
+}
+__device__ __forceinline__ void glds16_one(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
 __device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
     // two transposing reads: tokens +0..3 and +4..7 (rows are 256 B apart -> +1024 B)
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS s16x4*)(lds_addr));
@@ -94,7 +119,16 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// VAR 0: LDS-DMA issued in the LOAD half-phase, LEAD 6, generic per-unit source pointer.
+// VAR 1: LDS-DMA issued under the MFMAs of the MATH half-phase (LEAD 7), running source pointer.
+// VAR 2: as 0 with the running source pointer.
+// VAR 3: as 1 with the two LDS-DMA instructions of a unit apart (after the 2nd and the 5th MFMA).
+template <int VAR>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
+    constexpr bool IN_MATH = (VAR == 1 || VAR == 3);
+    constexpr bool SPLIT = (VAR == 3);
+    constexpr bool SLIM = (VAR >= 1);
+    constexpr int LEAD = IN_MATH ? 7 : 6;     // unit u+LEAD is issued in phase u
     // ONE LDS object: the ring.  Unit image: [4 channel groups: A-lo, A-hi, B-lo, B-hi][16 tokens][256 B].
     __shared__ __attribute__((aligned(16))) char ring[RING * UNIT_BYTES];
     const int tid = threadIdx.x;
@@ -152,19 +186,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     const unsigned voffA = (unsigned)((size_t)trow * ld2 + (size_t)colA * 2);
     const unsigned voffB = (unsigned)((size_t)trow * ld2 + (size_t)colB * 2);
     const unsigned ring_lds = (unsigned)(size_t)(QT_LDS char*)ring;
-    const unsigned dst_wave = ring_lds + (wave >> 2) * 4096 + (wave & 3) * 1024;  // wave-uniform
+    const unsigned dst_wave =
+        __builtin_amdgcn_readfirstlane(ring_lds + (wave >> 2) * 4096 + (wave & 3) * 1024);  // wave-uniform
 
-    auto unit_src = [&](int i) -> const char* {  // scalar: first token row of unit i
-        const int tt = tt0 + (i >> 2);
-        const char* base = (p.has_tail && tt == p.n_tt - 1) ? (const char*)p.tail
-                                                            : (const char*)p.X + (size_t)tt * BKT * ld2;
-        return base + (size_t)(i & 3) * UT * ld2;
+    // scalar source pointers: first token row of unit i.  The ragged last token tile (if this item
+    // reaches it) is read from the zero-padded staging; everything before it is contiguous in X.
+    const bool ends_in_tail = p.has_tail && (tt0 + cnt == p.n_tt);
+    const int i_tail = ends_in_tail ? nu - (BKT / UT) : 0x7fffffff;  // first unit taken from the staging
+    const size_t ustride = (size_t)UT * ld2;
+    auto unit_src = [&](int i) -> const char* {
+        return i >= i_tail ? (const char*)p.tail + (size_t)(i - i_tail) * ustride
+                           : (const char*)p.X + ((size_t)tt0 * BKT + (size_t)i * UT) * ld2;
     };
+    const char* run_src = (const char*)p.X + (size_t)tt0 * BKT * ld2;  // SLIM: pointer of the next unit to issue
     auto issue = [&](int i, int slot) {
-        const char* src = unit_src(i);
-        const unsigned d = __builtin_amdgcn_readfirstlane(dst_wave + (unsigned)slot * UNIT_BYTES);
-        glds16(voffA, src, d);
-        glds16(voffB, src, d + 8192);
+        const unsigned d = dst_wave + (unsigned)slot * UNIT_BYTES;
+        if (SLIM) glds16_pair(voffA, voffB, unit_src(i), d, d + 8192);
+        else {
+            glds16(voffA, unit_src(i), d);
+            glds16(voffB, unit_src(i), d + 8192);
+        }
+    };
+    // steady-state issue: no tail test, the source pointer just advances (units are consecutive rows)
+    auto issue_running = [&](int slot) {
+        const unsigned d = dst_wave + (unsigned)slot * UNIT_BYTES;
+        glds16_pair(voffA, voffB, run_src, d, d + 8192);
+        run_src += ustride;
+    };
+    auto issue_running_a = [&](int slot) { glds16_one(voffA, run_src, dst_wave + (unsigned)slot * UNIT_BYTES); };
+    auto issue_running_b = [&](int slot) {
+        glds16_one(voffB, run_src, dst_wave + (unsigned)slot * UNIT_BYTES + 8192);
+        run_src += ustride;
     };
 
     // ---- fragment read geometry (per lane), byte offsets inside a unit ----
@@ -191,50 +243,83 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     //   RAW: unit u is read in intervals 2u (A) / 2u+1 (B).  Every wave waits for its own DMA of
     //        unit u (counted vmcnt) in LOAD(u-1), i.e. in intervals 2u-2 / 2u-1, and the barrier
     //        that ends interval 2u-1 follows both: "read one phase after the wait that retires it".
-    //   WAR: unit u's reads retire at the lgkmcnt(0) in MATH(u): intervals 2u+1 (A) / 2u+2 (B).
-    //        Its slot is re-filled with unit u+8, issued in LOAD(u+2): intervals 2u+4 / 2u+5,
-    //        after the barriers that end 2u+2 and 2u+3.
+    //   WAR: unit u's reads retire at the lgkmcnt(0) that opens MATH(u): intervals 2u+1 (A) / 2u+2 (B).
+    //        Its slot is re-filled with unit u+8.  Issued in LOAD(u+2) (LEAD 6): intervals 2u+4 / 2u+5,
+    //        after the barriers that end 2u+2 and 2u+3.  Issued in MATH(u+1) (LEAD 7): intervals
+    //        2u+3 / 2u+4, after the barrier that ends 2u+2.
+    //   In flight at every wait: 5 units = 10 LDS-DMA instructions per wave (80 KiB per CU), both forms.
     bf16x8 fa[4], fb[2];
-    auto load_part = [&](auto slot_c, auto steady_c, int u) {
+    auto drain_wait = [&](int u) {
+        // no unit beyond nu-1 exists: allow exactly the units after u+1 to stay in flight
+        const int later = nu - u - 2;
+        if (later >= 5) wait_vmcnt<10>();
+        else if (later == 4) wait_vmcnt<8>();
+        else if (later == 3) wait_vmcnt<6>();
+        else if (later == 2) wait_vmcnt<4>();
+        else if (later == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+    auto phase = [&](auto slot_c, auto steady_c, int u) {
         constexpr int S = decltype(slot_c)::value;
         constexpr bool STEADY = decltype(steady_c)::value;
+        constexpr int ISLOT = (S + LEAD) & (RING - 1);
+        // ---- LOAD ----
         const char* base = ring + S * UNIT_BYTES;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) fa[mi] = tr_load8(base + aoff[mi]);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) fb[ni] = tr_load8(base + boff[ni]);
-        if (STEADY || u + LEAD < nu) {
-            issue(u + LEAD, (S + LEAD) & (RING - 1));
-            wait_vmcnt<2 * (LEAD - 1)>();  // everything up to unit u+1 has landed; 5 units stay in flight
+        if (!IN_MATH) {
+            if (STEADY) {
+                if (SLIM) issue_running(ISLOT);
+                else issue(u + LEAD, ISLOT);
+                wait_vmcnt<10>();
+            } else if (u + LEAD < nu) {
+                issue(u + LEAD, ISLOT);
+                wait_vmcnt<10>();
+            } else {
+                drain_wait(u);
+            }
         } else {
-            // drain: no further issue; allow exactly the units after u+1 to stay in flight
-            const int later = nu - u - 2;
-            if (later >= 4) wait_vmcnt<8>();
-            else if (later == 3) wait_vmcnt<6>();
-            else if (later == 2) wait_vmcnt<4>();
-            else if (later == 1) wait_vmcnt<2>();
-            else wait_vmcnt<0>();
+            // units up to u+LEAD-1 were issued (the last one under MATH(u-1)); unit u+1 must have landed
+            if (STEADY) wait_vmcnt<10>();
+            else drain_wait(u);   // exact for every u: min(5, nu-u-2) units may stay in flight
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-    };
-    auto math_part = [&]() {
+        // ---- MATH ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[0][1], 0, 0, 0);
+        if (IN_MATH) {
+            // the LDS-DMA of unit u+LEAD goes out under the MFMAs: its slot held unit u-1, whose last
+            // reads (group B's) retired before the barrier this wave has just passed
+            __builtin_amdgcn_sched_barrier(0);
+            if (STEADY) {
+                if (SPLIT) issue_running_a(ISLOT);
+                else issue_running(ISLOT);
+            } else if (u + LEAD < nu) {
+                issue(u + LEAD, ISLOT);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[1][1], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[2][0], 0, 0, 0);
+        if (IN_MATH && SPLIT && STEADY) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_running_b(ISLOT);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[1], acc[2][1], 0, 0, 0);
+        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[3], fb[0], acc[3][0], 0, 0, 0);
+        acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[3], fb[1], acc[3][1], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-    };
-    auto phase = [&](auto slot_c, auto steady_c, int u) {
-        load_part(slot_c, steady_c, u);
-        math_part();
     };
     auto body8 = [&](auto steady_c, int u) {
         phase(std::integral_constant<int, 0>{}, steady_c, u);
@@ -258,8 +343,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         if (group_b) __builtin_amdgcn_s_barrier();  // stagger: group B runs one interval behind
         __builtin_amdgcn_sched_barrier(0);
 
+        // steady body: every phase issues a unit that exists and does not come from the tail staging
+        const int steady_end = (nu < i_tail ? nu : i_tail);
+        run_src += (size_t)LEAD * ustride;
         int u = 0;
-        for (; u + 8 + LEAD <= nu; u += 8) body8(std::true_type{}, u);
+        for (; u + 8 + LEAD <= steady_end; u += 8) body8(std::true_type{}, u);
         for (; u + 8 <= nu; u += 8) body8(std::false_type{}, u);
         if (u < nu) {  // nu is a multiple of 4: one half body left
             phase(std::integral_constant<int, 0>{}, std::false_type{}, u);
@@ -483,7 +571,12 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     auto launch = [&](const XtxParams& q, const XtxPlan& ql) -> int {
         const int grid = ql.n_direct + ql.n_rem * ql.s2;
         qt_prof_mark(QT_PROF_XTX, stream);
-        hipLaunchKernelGGL(xtx_kernel, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        const char* ve = getenv("QT_XTX_VAR");
+        const int var = ve ? atoi(ve) : 1;
+        if (var == 0) hipLaunchKernelGGL(xtx_kernel<0>, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        else if (var == 2) hipLaunchKernelGGL(xtx_kernel<2>, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        else if (var == 3) hipLaunchKernelGGL(xtx_kernel<3>, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        else hipLaunchKernelGGL(xtx_kernel<1>, dim3(grid), dim3(NTHREADS), 0, stream, q);
         qt_prof_mark(QT_PROF_XTX, stream);
         QT_LAUNCH_CHECK();
         if (ql.n_rem > 0) {

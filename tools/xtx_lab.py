@@ -22,13 +22,17 @@ from quantool_amd.hip import ops
 DEV = torch.device("cuda:0")
 VARIANTS = {
     "v1": {"QT_XTX_IMPL": "0"},
-    "ring": {"QT_XTX_IMPL": "1", "QT_XTX_MAP": "0"},
-    "ring_map1": {"QT_XTX_IMPL": "1", "QT_XTX_MAP": "1"},
+    "ring0": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "0"},
+    "ring1": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "1"},
+    "ring2": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "2"},
+    "ring3": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "3"},
+    "ring1_map1": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "1", "QT_XTX_MAP": "1"},
 }
+CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "v1,ring0,ring1,ring2,ring3").split(",") if v]
 
 
 def setenv(v):
-    for k in ("QT_XTX_IMPL", "QT_XTX_MAP"):
+    for k in ("QT_XTX_IMPL", "QT_XTX_MAP", "QT_XTX_VAR"):
         os.environ.pop(k, None)
     os.environ.update(VARIANTS[v])
 
@@ -90,7 +94,7 @@ def check():
     for n, K in cases:
         X = synth(n, K, seed=n + K)
         row = []
-        for v in ("v1", "ring", "ring_map1"):
+        for v in CHECKED:
             G0 = gram(X, K, v)
             e = ref_err(X, G0, K)
             same = True
@@ -103,11 +107,11 @@ def check():
             dbl = float((torch.tril(G2) - 2 * torch.tril(G0)).abs().max() / torch.tril(G0).abs().max())
             good = e <= 1e-5 and same and dbl <= 1e-6
             ok &= good
-            row.append(f"{v}: err {e:.2e} det {same} 2x {dbl:.1e} {'ok' if good else 'FAIL'}")
+            row.append(f"{v}: {e:.1e} {'ok' if good else f'FAIL det={same} 2x={dbl:.1e}'}")
         # strided input (ldx > K)
         Xw = torch.zeros((n, K + 64), dtype=torch.bfloat16, device=DEV)
         Xw[:, :K] = X
-        setenv("ring")
+        setenv(CHECKED[-1])
         Gs = torch.zeros((K, K), dtype=torch.float32, device=DEV)
         ops.xtx_accumulate(Xw[:, :K], Gs)
         es = ref_err(X, Gs, K)
@@ -118,7 +122,8 @@ def check():
     return ok
 
 
-def timeit(Ks, n=196608, rounds=4, variants=("v1", "ring", "ring_map1")):
+def timeit(Ks, n=196608, rounds=5, variants=None):
+    variants = variants or CHECKED + ["ring1_map1"]
     for K in Ks:
         X = synth(n, K, seed=K)
         G = torch.zeros((K, K), dtype=torch.float32, device=DEV)
@@ -149,7 +154,7 @@ def staged(K=14336, n=196608, T=384):
     """Per-sample accumulation through HessianAccumulator's token staging vs one launch."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator
 
-    setenv("ring")
+    setenv("ring1")
     X = synth(n, K, seed=K + 1)
     one = HessianAccumulator(K, DEV, stage_tokens=0)
     st = HessianAccumulator(K, DEV)
