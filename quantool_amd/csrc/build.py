@@ -69,12 +69,39 @@ def _compile(src: Path) -> Path:
     return obj
 
 
+def audit_m0(src: Path) -> None:
+    """xtx.hip writes M0 from inline asm without restoring it (the LDS-DMA destination).  That is only
+    sound while hipcc itself never touches M0 in that translation unit, so the device ISA is checked:
+    every line that names m0 must sit inside an ;;#ASMSTART ... ;;#ASMEND block."""
+    stamp = OBJ_DIR / (src.stem + ".m0audit")
+    want = _stamp(src)
+    if stamp.exists() and stamp.read_text() == want:
+        return
+    asm = OBJ_DIR / (src.stem + ".device.s")
+    cmd = [_hipcc(), *[f for f in HIPCC_FLAGS if f != "-fPIC"], "--cuda-device-only", "-S", str(src), "-o", str(asm)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed for {src.name}:\n{res.stderr}")
+    inside = False
+    for n, line in enumerate(asm.read_text().splitlines(), 1):
+        if ";;#ASMSTART" in line:
+            inside = True
+        elif ";;#ASMEND" in line:
+            inside = False
+        elif not inside and "m0" in line.split(";")[0].replace("_m0", ""):
+            raise RuntimeError(f"{src.name}: compiler-generated use of M0 at {asm.name}:{n}: {line.strip()!r} -- "
+                               "the LDS-DMA helpers must save/restore M0 again")
+    asm.unlink()
+    stamp.write_text(want)
+
+
 def build(verbose: bool = False) -> Path:
     OBJ_DIR.mkdir(exist_ok=True)
     LIB_DIR.mkdir(exist_ok=True)
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
+    audit_m0(CSRC / "xtx.hip")
     newest = max(o.stat().st_mtime for o in objs)
     if not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]

@@ -33,11 +33,6 @@
 
 #include "common.h"
 
-// round-1 kernel (xtx_v1.hip), kept for same-process A/B runs: QT_XTX_IMPL=0
-size_t qt_xtx_v1_workspace_bytes(int64_t n_tokens, int K);
-int qt_xtx_v1_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G, void* workspace,
-                         size_t workspace_bytes, qt_stream_t stream_);
-
 namespace {
 
 constexpr int BT = 256;                       // output tile edge (channels)
@@ -62,24 +57,12 @@ struct XtxParams {
     float* slabs;   // [s2][n_rem][256*256]
     float* G;
     int map_mode;   // 0: rounds of 256 with XCD-contiguous blocks of 32; 1: identity
+    int wrap_units; // > 0: timing-only locality ablation (xtx_kernel<true>)
 };
 
 // LDS-DMA from inline asm: hipcc does not track it, so it inserts no vmcnt drain in front of later
 // ds_reads or barriers.  Every completion is ordered by hand (counted vmcnt + s_barrier below).
 // saddr form: 64-bit scalar base + 32-bit per-lane byte offset; M0 = wave-uniform LDS destination.
-__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-
 // Both LDS-DMA instructions of one unit (A panel, B panel) in one statement.  M0 is written in the
 // statement that reads it and is not restored: nothing else in this kernel uses M0 (LDS instructions
 // need none on gfx9+), which the build checks by grepping the kernel's ISA for m0 outside these blocks.
@@ -96,16 +79,6 @@ __device__ __forceinline__ void glds16_pair(unsigned voffA, unsigned voffB, cons
         : "v"(voffA), "v"(voffB), "s"(sbase), "s"(ldsA), "s"(ldsB)
         : "memory");
 }
-__device__ __forceinline__ void glds16_one(unsigned voff, const void* sbase, unsigned lds_dst) {
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %1"
-        :
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-
 __device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
     // two transposing reads: tokens +0..3 and +4..7 (rows are 256 B apart -> +1024 B)
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS s16x4*)(lds_addr));
@@ -119,16 +92,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// VAR 0: LDS-DMA issued in the LOAD half-phase, LEAD 6, generic per-unit source pointer.
-// VAR 1: LDS-DMA issued under the MFMAs of the MATH half-phase (LEAD 7), running source pointer.
-// VAR 2: as 0 with the running source pointer.
-// VAR 3: as 1 with the two LDS-DMA instructions of a unit apart (after the 2nd and the 5th MFMA).
-template <int VAR>
+// WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
+// pointer wraps every wrap_units units, so the footprint every workgroup streams is that window --
+// L2-resident for small windows, Infinity-Cache-resident for medium ones (profiles/r02_xtx_locality.md).
+template <bool WRAP>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
-    constexpr bool IN_MATH = (VAR == 1 || VAR == 3);
-    constexpr bool SPLIT = (VAR == 3);
-    constexpr bool SLIM = (VAR >= 1);
-    constexpr int LEAD = IN_MATH ? 7 : 6;     // unit u+LEAD is issued in phase u
+    constexpr int LEAD = 6;     // unit u+LEAD is issued in phase u  (LEAD <= RING-2, see the hazard analysis)
     // ONE LDS object: the ring.  Unit image: [4 channel groups: A-lo, A-hi, B-lo, B-hi][16 tokens][256 B].
     __shared__ __attribute__((aligned(16))) char ring[RING * UNIT_BYTES];
     const int tid = threadIdx.x;
@@ -198,25 +167,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         return i >= i_tail ? (const char*)p.tail + (size_t)(i - i_tail) * ustride
                            : (const char*)p.X + ((size_t)tt0 * BKT + (size_t)i * UT) * ld2;
     };
-    const char* run_src = (const char*)p.X + (size_t)tt0 * BKT * ld2;  // SLIM: pointer of the next unit to issue
+    const char* run_src = (const char*)p.X + (size_t)tt0 * BKT * ld2;  // pointer of the next unit to issue
     auto issue = [&](int i, int slot) {
         const unsigned d = dst_wave + (unsigned)slot * UNIT_BYTES;
-        if (SLIM) glds16_pair(voffA, voffB, unit_src(i), d, d + 8192);
-        else {
-            glds16(voffA, unit_src(i), d);
-            glds16(voffB, unit_src(i), d + 8192);
-        }
+        glds16_pair(voffA, voffB, unit_src(i), d, d + 8192);
     };
     // steady-state issue: no tail test, the source pointer just advances (units are consecutive rows)
+    int wrap_cnt = 0;
     auto issue_running = [&](int slot) {
         const unsigned d = dst_wave + (unsigned)slot * UNIT_BYTES;
         glds16_pair(voffA, voffB, run_src, d, d + 8192);
         run_src += ustride;
-    };
-    auto issue_running_a = [&](int slot) { glds16_one(voffA, run_src, dst_wave + (unsigned)slot * UNIT_BYTES); };
-    auto issue_running_b = [&](int slot) {
-        glds16_one(voffB, run_src, dst_wave + (unsigned)slot * UNIT_BYTES + 8192);
-        run_src += ustride;
+        if (WRAP && ++wrap_cnt == p.wrap_units) {
+            wrap_cnt = 0;
+            run_src -= (size_t)p.wrap_units * ustride;
+        }
     };
 
     // ---- fragment read geometry (per lane), byte offsets inside a unit ----
@@ -244,10 +209,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     //        unit u (counted vmcnt) in LOAD(u-1), i.e. in intervals 2u-2 / 2u-1, and the barrier
     //        that ends interval 2u-1 follows both: "read one phase after the wait that retires it".
     //   WAR: unit u's reads retire at the lgkmcnt(0) that opens MATH(u): intervals 2u+1 (A) / 2u+2 (B).
-    //        Its slot is re-filled with unit u+8.  Issued in LOAD(u+2) (LEAD 6): intervals 2u+4 / 2u+5,
-    //        after the barriers that end 2u+2 and 2u+3.  Issued in MATH(u+1) (LEAD 7): intervals
-    //        2u+3 / 2u+4, after the barrier that ends 2u+2.
-    //   In flight at every wait: 5 units = 10 LDS-DMA instructions per wave (80 KiB per CU), both forms.
+    //        Its slot is re-filled with unit u+8, issued in LOAD(u+2): intervals 2u+4 / 2u+5, after
+    //        the barriers that end 2u+2 and 2u+3.  (LEAD 7 would put group A's issue into 2u+2, beside
+    //        group B's outstanding reads.)
+    //   In flight at every wait: 5 units = 10 LDS-DMA instructions per wave (80 KiB per CU).
     bf16x8 fa[4], fb[2];
     auto drain_wait = [&](int u) {
         // no unit beyond nu-1 exists: allow exactly the units after u+1 to stay in flight
@@ -269,21 +234,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         for (int mi = 0; mi < 4; ++mi) fa[mi] = tr_load8(base + aoff[mi]);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) fb[ni] = tr_load8(base + boff[ni]);
-        if (!IN_MATH) {
-            if (STEADY) {
-                if (SLIM) issue_running(ISLOT);
-                else issue(u + LEAD, ISLOT);
-                wait_vmcnt<10>();
-            } else if (u + LEAD < nu) {
-                issue(u + LEAD, ISLOT);
-                wait_vmcnt<10>();
-            } else {
-                drain_wait(u);
-            }
+        if (STEADY) {
+            issue_running(ISLOT);
+            wait_vmcnt<10>();   // everything up to unit u+1 has landed; 5 units stay in flight
+        } else if (u + LEAD < nu) {
+            issue(u + LEAD, ISLOT);
+            wait_vmcnt<10>();
         } else {
-            // units up to u+LEAD-1 were issued (the last one under MATH(u-1)); unit u+1 must have landed
-            if (STEADY) wait_vmcnt<10>();
-            else drain_wait(u);   // exact for every u: min(5, nu-u-2) units may stay in flight
+            drain_wait(u);
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -291,31 +249,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[0][1], 0, 0, 0);
-        if (IN_MATH) {
-            // the LDS-DMA of unit u+LEAD goes out under the MFMAs: its slot held unit u-1, whose last
-            // reads (group B's) retired before the barrier this wave has just passed
-            __builtin_amdgcn_sched_barrier(0);
-            if (STEADY) {
-                if (SPLIT) issue_running_a(ISLOT);
-                else issue_running(ISLOT);
-            } else if (u + LEAD < nu) {
-                issue(u + LEAD, ISLOT);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[1][1], 0, 0, 0);
-        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[2][0], 0, 0, 0);
-        if (IN_MATH && SPLIT && STEADY) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_running_b(ISLOT);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[1], acc[2][1], 0, 0, 0);
-        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[3], fb[0], acc[3][0], 0, 0, 0);
-        acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[3], fb[1], acc[3][1], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -499,23 +437,16 @@ const int* xtx_host_table(int K, int n_tiles) {
     return pinned;
 }
 
-int xtx_impl() {
-    const char* e = getenv("QT_XTX_IMPL");
-    return e ? atoi(e) : 1;
-}
-
 }  // namespace
 
 extern "C" size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K) {
     if (n_tokens <= 0 || K <= 0) return 0;
-    if (xtx_impl() == 0) return qt_xtx_v1_workspace_bytes(n_tokens, K);
     XtxPlan pl = xtx_plan(n_tokens, K);
     return pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
 }
 
 extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G,
                                  void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
-    if (xtx_impl() == 0) return qt_xtx_v1_accumulate(X, n_tokens, K, ldx, G, workspace, workspace_bytes, stream_);
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(K > 0 && K % 8 == 0, "qt_xtx_accumulate: K=%d must be a positive multiple of 8", K);
     QT_CHECK_ARG(ldx >= K && ldx % 8 == 0, "qt_xtx_accumulate: ldx=%lld must be >= K and a multiple of 8", (long long)ldx);
@@ -561,6 +492,10 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
         const char* e = getenv("QT_XTX_MAP");
         p.map_mode = e ? atoi(e) : 0;
     }
+    {
+        const char* e = getenv("QT_XTX_ABLATE_WRAP");  // timing-only ablation, see xtx_kernel<true>
+        p.wrap_units = e ? atoi(e) : 0;
+    }
     if (pl.has_tail) {
         const int64_t full = n_tokens / BKT * BKT;
         const int64_t tail_rows = n_tokens - full;
@@ -571,12 +506,8 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     auto launch = [&](const XtxParams& q, const XtxPlan& ql) -> int {
         const int grid = ql.n_direct + ql.n_rem * ql.s2;
         qt_prof_mark(QT_PROF_XTX, stream);
-        const char* ve = getenv("QT_XTX_VAR");
-        const int var = ve ? atoi(ve) : 1;
-        if (var == 0) hipLaunchKernelGGL(xtx_kernel<0>, dim3(grid), dim3(NTHREADS), 0, stream, q);
-        else if (var == 2) hipLaunchKernelGGL(xtx_kernel<2>, dim3(grid), dim3(NTHREADS), 0, stream, q);
-        else if (var == 3) hipLaunchKernelGGL(xtx_kernel<3>, dim3(grid), dim3(NTHREADS), 0, stream, q);
-        else hipLaunchKernelGGL(xtx_kernel<1>, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        if (q.wrap_units > 0) hipLaunchKernelGGL(xtx_kernel<true>, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        else hipLaunchKernelGGL(xtx_kernel<false>, dim3(grid), dim3(NTHREADS), 0, stream, q);
         qt_prof_mark(QT_PROF_XTX, stream);
         QT_LAUNCH_CHECK();
         if (ql.n_rem > 0) {

@@ -2,7 +2,7 @@
 """Gram-kernel lab: correctness screen + same-process A/B timing of xtx_kernel variants (diagnostic).
 
 Variants are selected through the environment knobs the library reads per call
-(QT_XTX_IMPL 0 = round-1 two-stage kernel, 1 = ring kernel; QT_XTX_MAP).  Timings are interleaved
+(QT_XTX_MAP, QT_XTX_ABLATE_WRAP).  Timings are interleaved
 rounds in ONE process (guide rule 24); every variant is checked against an fp64 Gram matrix and
 for run-to-run bitwise determinism (a race in the hand-ordered LDS-DMA pipeline shows as either).
 
@@ -21,18 +21,16 @@ from quantool_amd.hip import ops
 
 DEV = torch.device("cuda:0")
 VARIANTS = {
-    "v1": {"QT_XTX_IMPL": "0"},
-    "ring0": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "0"},
-    "ring1": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "1"},
-    "ring2": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "2"},
-    "ring3": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "3"},
-    "ring1_map1": {"QT_XTX_IMPL": "1", "QT_XTX_VAR": "1", "QT_XTX_MAP": "1"},
+    "ring": {},
+    "ring_map1": {"QT_XTX_MAP": "1"},
+    "wrap8": {"QT_XTX_ABLATE_WRAP": "8"},          # timing-only ablations (wrong results)
+    "wrap64": {"QT_XTX_ABLATE_WRAP": "64"},
 }
-CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "v1,ring0,ring1,ring2,ring3").split(",") if v]
+CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "ring,ring_map1").split(",") if v]
 
 
 def setenv(v):
-    for k in ("QT_XTX_IMPL", "QT_XTX_MAP", "QT_XTX_VAR"):
+    for k in ("QT_XTX_MAP", "QT_XTX_ABLATE_WRAP"):
         os.environ.pop(k, None)
     os.environ.update(VARIANTS[v])
 
@@ -123,7 +121,7 @@ def check():
 
 
 def timeit(Ks, n=196608, rounds=5, variants=None):
-    variants = variants or CHECKED + ["ring1_map1"]
+    variants = variants or [v for v in os.environ.get("XTX_LAB_TIME", "").split(",") if v] or CHECKED + ["wrap8", "wrap64"]
     for K in Ks:
         X = synth(n, K, seed=K)
         G = torch.zeros((K, K), dtype=torch.float32, device=DEV)
@@ -154,7 +152,7 @@ def staged(K=14336, n=196608, T=384):
     """Per-sample accumulation through HessianAccumulator's token staging vs one launch."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator
 
-    setenv("ring1")
+    setenv("ring")
     X = synth(n, K, seed=K + 1)
     one = HessianAccumulator(K, DEV, stage_tokens=0)
     st = HessianAccumulator(K, DEV)
