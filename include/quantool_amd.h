@@ -44,21 +44,24 @@ int qt_version(void);
 const char* qt_last_error(void);
 
 /* ---- a7  accumulate_hessian (GPTQ hook under base.py:161) ----------------------------------
- * G[K,K] (fp32, lower triangle incl. diagonal tiles) += X^T X for X[n_tokens,K] bf16.
+ * G[K,K] (fp32, lower triangle incl. diagonal tiles) += X^T X for X[n_tokens,K] in the model's
+ * own 16-bit dtype (x_dtype QT_BF16 or QT_F16: the reference injects no dtype, base.py:222-241, and
+ * upstream accumulates inp.float() -- both products are exact in the fp32 accumulator).
  * The caller keeps the raw Gram sum G and the sample count n; upstream's running
  * "H = H*n/(n+1) + (2/(n+1)) X^T X" equals (2/n)*G and is applied in qt_hessian_prepare.
- * Requires K % 8 == 0, ldx % 8 == 0, X 16-byte aligned.  Deterministic (fixed split + ordered
- * slab reduction, no atomics). */
+ * Requires K % 8 == 0, ldx % 8 == 0, X 16-byte aligned.  Deterministic: a tile is either summed
+ * by one workgroup over all tokens and added to G, or split over token chunks whose fp32 slabs are
+ * reduced in fixed order -- no atomics. */
 size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K);
-int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G,
+int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, float* G,
                       void* workspace, size_t workspace_bytes, qt_stream_t stream);
 
 /* ---- a12/a13  activation statistics (AWQ / SmoothQuant hooks under base.py:161) ------------
  * abs_sum[K] += sum_t |x[t,k]|;  cmin[k] = min(cmin[k], min_t x);  cmax likewise.  Any of the
  * three outputs may be NULL.  The caller initialises abs_sum = 0, cmin = +inf, cmax = -inf.
- * X bf16 [n_tokens, K], K % 8 == 0.  Deterministic (ordered chunk reduction). */
+ * X [n_tokens, K] bf16 or fp16 (x_dtype), K % 8 == 0.  Deterministic (ordered chunk reduction). */
 size_t qt_act_stats_workspace_bytes(int64_t n_tokens, int K);
-int qt_act_stats_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* abs_sum,
+int qt_act_stats_accumulate(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, float* abs_sum,
                             float* cmin, float* cmax, void* workspace, size_t workspace_bytes,
                             qt_stream_t stream);
 
@@ -91,7 +94,7 @@ int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* wo
                               size_t workspace_bytes, qt_stream_t stream);
 
 /* ---- a10  minmax observer -> calculate_qparams ----------------------------------------------
- * W[R,K] (fp32 or bf16 by w_dtype) -> scale, zp [R, K/group_size] fp32.  group_size <= 0:
+ * W[R,K] (fp32, bf16 or fp16 by w_dtype -- every w_dtype / out_dtype argument below takes the three) -> scale, zp [R, K/group_size] fp32.  group_size <= 0:
  * channel-wise.  symmetric: scale = absmax/((qmax-qmin)/2), zp = 0.  scale_t / zp_t (may be
  * NULL) receive the same values group-major [G, R], the layout qt_gptq_sweep reads (one
  * coalesced load per column step: lanes are rows). */
@@ -125,7 +128,8 @@ int qt_pack_int4(const int8_t* Qt, int R, int K, const int32_t* col_src, int32_t
                  qt_stream_t stream);
 
 /* Dequantised weights in original column order: out[r,c] = (q - zp[r,g(c)]) * scale[r,g(c)],
- * out dtype by out_dtype (fp32/bf16); g_of_col int32[K] group of each ORIGINAL column. */
+ * out dtype by out_dtype (fp32 / bf16 / fp16, round to nearest even); g_of_col int32[K] group of each
+ * ORIGINAL column. */
 int qt_dequantize(const int8_t* Qt, int R, int K, const int32_t* col_src, const float* scale,
                   const float* zp, int G, const int32_t* g_of_col, void* out, int out_dtype,
                   int64_t ldo, qt_stream_t stream);

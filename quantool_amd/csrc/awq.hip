@@ -15,10 +15,6 @@
 
 namespace {
 
-__device__ __forceinline__ float load_w(const void* W, int dtype, size_t idx) {
-    if (dtype == QT_F32) return ((const float*)W)[idx];
-    return qt_bf16_to_f32(((const unsigned short*)W)[idx]);
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -49,7 +45,7 @@ __global__ __launch_bounds__(64) void awq_wmean_partial_kernel(const void* __res
         for (int e = 0; e < 8; ++e) {
             v[e] = 0.0f;
             if (e < per) {
-                v[e] = fabsf(load_w(W, dtype, (size_t)r * ldw + (size_t)g * gs + e * 64 + lane));
+                v[e] = fabsf(qt_load_w(W, dtype, (size_t)r * ldw + (size_t)g * gs + e * 64 + lane));
                 m = fmaxf(m, v[e]);
             }
         }
@@ -70,7 +66,7 @@ __global__ __launch_bounds__(64) void row_group_absmax_kernel(const void* __rest
                                                               int64_t ldw, int gs, float* __restrict__ amax) {
     const int g = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
     float m = 0.0f;
-    for (int c = lane; c < gs; c += 64) m = fmaxf(m, fabsf(load_w(W, dtype, (size_t)r * ldw + (size_t)g * gs + c)));
+    for (int c = lane; c < gs; c += 64) m = fmaxf(m, fabsf(qt_load_w(W, dtype, (size_t)r * ldw + (size_t)g * gs + c)));
     m = wave_max(m);
     if (lane == 0) amax[(size_t)r * (K / gs) + g] = m;
 }
@@ -86,7 +82,7 @@ __global__ __launch_bounds__(256) void awq_wmean_cols_kernel(const void* __restr
     float acc = 0.0f;
     for (int r = r0; r < r1; ++r) {
         const float m = amax[(size_t)r * G + g] + 1e-6f;
-        acc = acc + fabsf(load_w(W, dtype, (size_t)r * ldw + k)) / m;
+        acc = acc + fabsf(qt_load_w(W, dtype, (size_t)r * ldw + k)) / m;
     }
     partial[(size_t)chunk * K + k] = acc;
 }
@@ -157,7 +153,7 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
         float mx = -INFINITY, mn = INFINITY, amax = 0.0f;
         for (int c = lane; c < gs; c += 64) {
             const int k = g * gs + c;
-            const float v = load_w(W, dtype, (size_t)r * ldw + k) * s[k];
+            const float v = qt_load_w(W, dtype, (size_t)r * ldw + k) * s[k];
             mx = fmaxf(mx, v);
             mn = fminf(mn, v);
             amax = fmaxf(amax, fabsf(v));
@@ -167,7 +163,7 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
         amax = wave_max(amax);
         for (int c = lane; c < gs; c += 64) {
             const int k = g * gs + c;
-            const float wv = load_w(W, dtype, (size_t)r * ldw + k);
+            const float wv = qt_load_w(W, dtype, (size_t)r * ldw + k);
             const float v = wv * s[k];
             float q;
             if (symmetric) {
@@ -180,13 +176,8 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
                 const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
                 q = (fminf(fmaxf(rintf(v / sc) + z, 0.0f), max_int) - z) * sc;
             }
-            if (DIFF) {
-                ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(wv - q / s[k]);
-            } else if (dtype == QT_F32) {
-                ((float*)out)[(size_t)r * ldo + k] = q / s[k];
-            } else {
-                ((__bf16*)out)[(size_t)r * ldo + k] = (__bf16)(q / s[k]);
-            }
+            if (DIFF) ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(wv - q / s[k]);
+            else qt_store_w(out, dtype, (size_t)r * ldo + k, q / s[k]);
         }
         return;
     }
@@ -197,7 +188,7 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
         w[e] = ws[e] = 0.0f;
         if (e < per) {
             const int k = g * gs + e * 64 + lane;
-            w[e] = load_w(W, dtype, (size_t)r * ldw + k);
+            w[e] = qt_load_w(W, dtype, (size_t)r * ldw + k);
             ws[e] = w[e] * s[k];
             mx = fmaxf(mx, ws[e]);
             mn = fminf(mn, ws[e]);
@@ -222,13 +213,8 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
                 const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
                 q = (fminf(fmaxf(rintf(ws[e] / sc) + z, 0.0f), max_int) - z) * sc;
             }
-            if (DIFF) {
-                ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(w[e] - q / s[k]);
-            } else if (dtype == QT_F32) {
-                ((float*)out)[(size_t)r * ldo + k] = q / s[k];
-            } else {
-                ((__bf16*)out)[(size_t)r * ldo + k] = (__bf16)(q / s[k]);
-            }
+            if (DIFF) ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(w[e] - q / s[k]);
+            else qt_store_w(out, dtype, (size_t)r * ldo + k, q / s[k]);
         }
     }
 }
@@ -279,10 +265,9 @@ __global__ __launch_bounds__(256) void scale_columns_kernel(const void* __restri
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (k >= K) return;
-    const float w = load_w(W, dtype, (size_t)r * ldw + k);
+    const float w = qt_load_w(W, dtype, (size_t)r * ldw + k);
     const float v = divide ? w / s[k] : w * s[k];
-    if (dtype == QT_F32) ((float*)out)[(size_t)r * ldo + k] = v;
-    else ((__bf16*)out)[(size_t)r * ldo + k] = (__bf16)v;
+    qt_store_w(out, dtype, (size_t)r * ldo + k, v);
 }
 
 // cmax[k] = max(cmax[k], max_r |W[r][k]|): thread per column, rows strided over blockIdx.y chunks
@@ -292,7 +277,7 @@ __global__ __launch_bounds__(256) void col_absmax_partial_kernel(const void* __r
     if (k >= K) return;
     const int r0 = blockIdx.y * rows_per, r1 = (r0 + rows_per < R) ? r0 + rows_per : R;
     float m = 0.0f;
-    for (int r = r0; r < r1; ++r) m = fmaxf(m, fabsf(load_w(W, dtype, (size_t)r * ldw + k)));
+    for (int r = r0; r < r1; ++r) m = fmaxf(m, fabsf(qt_load_w(W, dtype, (size_t)r * ldw + k)));
     part[(size_t)blockIdx.y * K + k] = m;
 }
 __global__ __launch_bounds__(256) void chunk_max_kernel(const float* __restrict__ part, int n_chunks, int K,
@@ -328,7 +313,7 @@ __global__ __launch_bounds__(256) void rtn_kernel(const void* __restrict__ W, in
         if (r < R && c < K) {
             const int g = c / gs;
             const float sc = scale[(size_t)r * G + g], z = zp[(size_t)r * G + g];
-            float x = load_w(W, dtype, (size_t)r * ldw + c) / sc;
+            float x = qt_load_w(W, dtype, (size_t)r * ldw + c) / sc;
             x = x + z;
             x = fminf(fmaxf(x, qmin), qmax);
             q = (int8_t)rintf(x);
@@ -356,7 +341,7 @@ extern "C" int qt_awq_weight_mean_accumulate(const void* W, int w_dtype, int R, 
                                              qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && w_sum && R > 0 && K > 0, "qt_awq_weight_mean_accumulate: bad arguments");
-    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_awq_weight_mean_accumulate: dtype");
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_awq_weight_mean_accumulate: dtype");
     const int gs = group_size <= 0 ? K : group_size;
     if (K % gs != 0) {
         qt_set_error("qt_awq_weight_mean_accumulate: group_size %d does not divide K", gs);
@@ -442,7 +427,7 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
                        gs, symmetric, num_bits, (void*)Db, (int64_t)K);
     QT_LAUNCH_CHECK();
     QT_HIP(hipMemsetAsync(C, 0, (size_t)K * K * 4, stream));
-    const int rc = qt_xtx_accumulate(Db, R, K, K, C, xws, xws_bytes, stream_);
+    const int rc = qt_xtx_accumulate(Db, QT_BF16, R, K, K, C, xws, xws_bytes, stream_);
     if (rc) return rc;
     hipLaunchKernelGGL(sym_dot_rows_kernel, dim3(K), dim3(256), 0, stream, Gfull, (const float*)C, K, partial);
     QT_LAUNCH_CHECK();
@@ -457,14 +442,14 @@ extern "C" int qt_awq_pseudo_quantize(const void* W, int w_dtype, int R, int K, 
                                        qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && s && out && R > 0 && K > 0, "qt_awq_pseudo_quantize: bad arguments");
-    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_awq_pseudo_quantize: dtype %d unsupported", w_dtype);
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_awq_pseudo_quantize: dtype %d unsupported", w_dtype);
     QT_CHECK_ARG(num_bits >= 2 && num_bits <= 8, "qt_awq_pseudo_quantize: num_bits=%d", num_bits);
     const int gs = group_size <= 0 ? K : group_size;
     if (K % gs != 0) {
         qt_set_error("qt_awq_pseudo_quantize: group_size %d unsupported", gs);
         return QT_ERR_UNSUPPORTED;
     }
-    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    const size_t esz = qt_dtype_size(w_dtype);
     for (int row0 = 0; row0 < R; row0 += 32768) {   // gridDim.y limit
         const int rows = (R - row0 < 32768) ? R - row0 : 32768;
         hipLaunchKernelGGL(awq_pseudo_quant_kernel<false>, dim3(K / gs, rows), dim3(64), 0, stream,
@@ -479,8 +464,8 @@ extern "C" int qt_scale_columns(const void* W, int w_dtype, int R, int K, int64_
                                 void* out, int64_t ldo, qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && s && out && R > 0 && K > 0, "qt_scale_columns: bad arguments");
-    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_scale_columns: dtype");
-    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_scale_columns: dtype");
+    const size_t esz = qt_dtype_size(w_dtype);
     for (int row0 = 0; row0 < R; row0 += 32768) {  // gridDim.y <= 65535
         const int rows = (R - row0 < 32768) ? R - row0 : 32768;
         hipLaunchKernelGGL(scale_columns_kernel, dim3((K + 255) / 256, rows), dim3(256), 0, stream,

@@ -9,6 +9,7 @@
 #include "../../include/quantool_amd.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -74,3 +75,24 @@ struct QtOncePerDevice {
 __device__ __forceinline__ float qt_bf16_to_f32(unsigned short h) {
     return __uint_as_float(((unsigned)h) << 16);
 }
+__device__ __forceinline__ float qt_f16_to_f32(unsigned short h) {
+    return (float)__builtin_bit_cast(_Float16, h);   // exact
+}
+// 16-bit element (bf16 or IEEE half by dtype) -> fp32, exact
+__device__ __forceinline__ float qt_h16_to_f32(unsigned short h, int dtype) {
+    return dtype == QT_F16 ? qt_f16_to_f32(h) : qt_bf16_to_f32(h);
+}
+// element idx of a weight / activation matrix stored as fp32, bf16 or fp16 -> fp32 (upstream: .float())
+__device__ __forceinline__ float qt_load_w(const void* W, int dtype, size_t idx) {
+    if (dtype == QT_F32) return ((const float*)W)[idx];
+    return qt_h16_to_f32(((const unsigned short*)W)[idx], dtype);
+}
+// fp32 -> the tensor's dtype, round to nearest even (upstream: .to(dtype))
+__device__ __forceinline__ void qt_store_w(void* out, int dtype, size_t idx, float v) {
+    if (dtype == QT_F32) ((float*)out)[idx] = v;
+    else if (dtype == QT_F16) ((_Float16*)out)[idx] = (_Float16)v;
+    else ((__bf16*)out)[idx] = (__bf16)v;
+}
+static inline bool qt_dtype_ok(int d) { return d == QT_F32 || d == QT_BF16 || d == QT_F16; }
+static inline bool qt_dtype_is16(int d) { return d == QT_BF16 || d == QT_F16; }
+static inline size_t qt_dtype_size(int d) { return d == QT_F32 ? 4 : 2; }

@@ -6,10 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ float load_w(const void* W, int dtype, size_t idx) {
-    if (dtype == QT_F32) return ((const float*)W)[idx];
-    return qt_bf16_to_f32(((const unsigned short*)W)[idx]);
-}
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -32,7 +28,7 @@ __global__ __launch_bounds__(64) void qparams_kernel(const void* __restrict__ W,
     const size_t base = (size_t)r * ldw + (size_t)g * gs;
     float mn = INFINITY, mx = -INFINITY;
     for (int c = lane; c < gs; c += 64) {
-        const float w = load_w(W, dtype, base + c);
+        const float w = qt_load_w(W, dtype, base + c);
         mn = fminf(mn, w);
         mx = fmaxf(mx, w);
     }
@@ -69,7 +65,7 @@ __global__ __launch_bounds__(256) void gather_f32_kernel(const void* __restrict_
     const int r = blockIdx.y;
     if (s >= K) return;
     const int src = perm ? perm[s] : s;
-    float v = load_w(W, dtype, (size_t)r * ldw + src);
+    float v = qt_load_w(W, dtype, (size_t)r * ldw + src);
     if (dead && dead[s]) v = 0.0f;
     out[(size_t)r * K + s] = v;
 }
@@ -136,11 +132,7 @@ __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__
             const float q = tile[rl][cl];
             const float z = zp[(size_t)r * G + g];
             const float v = (q - z) * scale[(size_t)r * G + g];
-            if (out_dtype == QT_F32) {
-                ((float*)out)[(size_t)r * ldo + c] = v;
-            } else {
-                ((__bf16*)out)[(size_t)r * ldo + c] = (__bf16)v;
-            }
+            qt_store_w(out, out_dtype, (size_t)r * ldo + c, v);
         }
     }
 }
@@ -157,14 +149,14 @@ extern "C" int qt_group_minmax_qparams(const void* W, int w_dtype, int R, int K,
                                        float* zp_t, qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && scale && zp && R > 0 && K > 0, "qt_group_minmax_qparams: bad arguments");
-    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_group_minmax_qparams: dtype %d unsupported", w_dtype);
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_group_minmax_qparams: dtype %d unsupported", w_dtype);
     QT_CHECK_ARG(num_bits >= 2 && num_bits <= 8, "qt_group_minmax_qparams: num_bits=%d", num_bits);
     const int gs = group_size <= 0 ? K : group_size;
     QT_CHECK_ARG(K % gs == 0, "qt_group_minmax_qparams: K=%d not divisible by group_size=%d", K, gs);
     float qmin, qmax;
     qt_range(num_bits, &qmin, &qmax);
     // gridDim.y is limited to 65535: rows are processed in chunks (row0 offsets every pointer)
-    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    const size_t esz = qt_dtype_size(w_dtype);
     const int G = K / gs;
     for (int row0 = 0; row0 < R; row0 += 32768) {
         const int rows = (R - row0 < 32768) ? R - row0 : 32768;
@@ -181,8 +173,8 @@ extern "C" int qt_weight_gather_f32(const void* W, int w_dtype, int R, int K, in
                                     const uint8_t* dead, float* W_f32, qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && W_f32 && R > 0 && K > 0, "qt_weight_gather_f32: bad arguments");
-    QT_CHECK_ARG(w_dtype == QT_F32 || w_dtype == QT_BF16, "qt_weight_gather_f32: dtype %d unsupported", w_dtype);
-    const size_t esz = (w_dtype == QT_F32) ? 4 : 2;
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_weight_gather_f32: dtype %d unsupported", w_dtype);
+    const size_t esz = qt_dtype_size(w_dtype);
     for (int row0 = 0; row0 < R; row0 += 32768) {
         const int rows = (R - row0 < 32768) ? R - row0 : 32768;
         hipLaunchKernelGGL(gather_f32_kernel, dim3((K + 255) / 256, rows), dim3(256), 0, stream,
@@ -209,7 +201,7 @@ extern "C" int qt_dequantize(const int8_t* Qt, int R, int K, const int32_t* col_
                              qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(Qt && scale && zp && g_of_col && out && R > 0 && K > 0 && G > 0, "qt_dequantize: bad arguments");
-    QT_CHECK_ARG(out_dtype == QT_F32 || out_dtype == QT_BF16, "qt_dequantize: dtype %d unsupported", out_dtype);
+    QT_CHECK_ARG(qt_dtype_ok(out_dtype), "qt_dequantize: dtype %d unsupported", out_dtype);
     hipLaunchKernelGGL(dequant_kernel, dim3((K + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, Qt, R, K, col_src,
                        scale, zp, G, g_of_col, out, out_dtype, ldo);
     QT_LAUNCH_CHECK();

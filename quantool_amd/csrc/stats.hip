@@ -1,6 +1,6 @@
 // a12 / a13 activation statistics: per-channel sum |x| over tokens
 // (AWQ's x_mean numerator) and running per-channel min / max (SmoothQuant).  HBM-bound: one
-// 16-byte load per lane (8 bf16 channels), token chunks across workgroups, then an ordered
+// 16-byte load per lane (8 bf16 / fp16 channels), token chunks across workgroups, then an ordered
 // reduction over chunks (deterministic; no atomics).
 #include "common.h"
 
@@ -31,7 +31,7 @@ StatsPlan stats_plan(int64_t n_tokens, int K) {
 __global__ __launch_bounds__(TPB) void act_stats_partial_kernel(const unsigned short* __restrict__ X,
                                                                 int64_t n_tokens, int K, int64_t ldx,
                                                                 int64_t tokens_per_chunk,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, int dtype) {
     const int c0 = (blockIdx.x * TPB + threadIdx.x) * 8;
     const int chunk = blockIdx.y;
     if (c0 >= K) return;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(TPB) void act_stats_partial_kernel(const unsigned s
         const s16x8 v = *(const s16x8*)(X + (size_t)t * ldx + c0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float f = qt_bf16_to_f32((unsigned short)v[e]);
+            const float f = qt_h16_to_f32((unsigned short)v[e], dtype);
             s[e] = s[e] + fabsf(f);
             mn[e] = fminf(mn[e], f);
             mx[e] = fmaxf(mx[e], f);
@@ -89,10 +89,11 @@ extern "C" size_t qt_act_stats_workspace_bytes(int64_t n_tokens, int K) {
     return (size_t)pl.n_chunks * 3 * K * 4 + 256;
 }
 
-extern "C" int qt_act_stats_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* abs_sum,
+extern "C" int qt_act_stats_accumulate(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, float* abs_sum,
                                        float* cmin, float* cmax, void* workspace, size_t workspace_bytes,
                                        qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(qt_dtype_is16(x_dtype), "qt_act_stats_accumulate: x_dtype %d must be QT_BF16 or QT_F16", x_dtype);
     QT_CHECK_ARG(K > 0 && K % 8 == 0 && ldx >= K && ldx % 8 == 0, "qt_act_stats_accumulate: K=%d ldx=%lld must be multiples of 8", K, (long long)ldx);
     if (n_tokens <= 0) return QT_OK;
     QT_CHECK_ARG(X && ((uintptr_t)X & 15) == 0, "qt_act_stats_accumulate: X must be non-null, 16-byte aligned");
@@ -104,7 +105,7 @@ extern "C" int qt_act_stats_accumulate(const void* X, int64_t n_tokens, int K, i
     StatsPlan pl = stats_plan(n_tokens, K);
     float* partial = (float*)qt_align_up((size_t)workspace, 256);
     hipLaunchKernelGGL(act_stats_partial_kernel, dim3(pl.strips, pl.n_chunks), dim3(TPB), 0, stream,
-                       (const unsigned short*)X, n_tokens, K, ldx, pl.tokens_per_chunk, partial);
+                       (const unsigned short*)X, n_tokens, K, ldx, pl.tokens_per_chunk, partial, x_dtype);
     QT_LAUNCH_CHECK();
     hipLaunchKernelGGL(act_stats_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, (const float*)partial,
                        pl.n_chunks, K, abs_sum, cmin, cmax);

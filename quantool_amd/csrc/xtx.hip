@@ -44,8 +44,8 @@ constexpr int NTHREADS = 512;                 // 8 waves: 2 (M) x 4 (N), 128x64 
 constexpr int NUM_CU = 256;
 
 struct XtxParams {
-    const __bf16* X;
-    const __bf16* tail;  // zero-padded [64, ldx] staging of the ragged last token tile
+    const void* X;       // [tokens, ldx] 16-bit elements (bf16 or fp16: the kernel is instantiated for each)
+    const void* tail;    // zero-padded [64, K] staging of the ragged last token tile
     int64_t ldx;
     int K;
     int n_tt;       // token tiles (of 64) including the tail tile
@@ -79,12 +79,21 @@ __device__ __forceinline__ void glds16_pair(unsigned voffA, unsigned voffB, cons
         : "v"(voffA), "v"(voffB), "s"(sbase), "s"(ldsA), "s"(ldsB)
         : "memory");
 }
-__device__ __forceinline__ bf16x8 tr_load8(const char* lds_addr) {
+__device__ __forceinline__ s16x8 tr_load8(const char* lds_addr) {
     // two transposing reads: tokens +0..3 and +4..7 (rows are 256 B apart -> +1024 B)
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS s16x4*)(lds_addr));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS s16x4*)(lds_addr + 1024));
-    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// one k-step (16 tokens) of a 32x32 output tile; bf16 and fp16 products are both exact in the fp32
+// accumulator and run at the same MFMA rate, so the checkpoint's own dtype is used as it is
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 template <int N>
@@ -95,7 +104,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
 // pointer wraps every wrap_units units, so the footprint every workgroup streams is that window --
 // L2-resident for small windows, Infinity-Cache-resident for medium ones (profiles/r02_xtx_locality.md).
-template <bool WRAP>
+template <bool WRAP, bool F16>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     constexpr int LEAD = 6;     // unit u+LEAD is issued in phase u  (LEAD <= RING-2, see the hazard analysis)
     // ONE LDS object: the ring.  Unit image: [4 channel groups: A-lo, A-hi, B-lo, B-hi][16 tokens][256 B].
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     //        the barriers that end 2u+2 and 2u+3.  (LEAD 7 would put group A's issue into 2u+2, beside
     //        group B's outstanding reads.)
     //   In flight at every wait: 5 units = 10 LDS-DMA instructions per wave (80 KiB per CU).
-    bf16x8 fa[4], fb[2];
+    s16x8 fa[4], fb[2];
     auto drain_wait = [&](int u) {
         // no unit beyond nu-1 exists: allow exactly the units after u+1 to stay in flight
         const int later = nu - u - 2;
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = mfma16<F16>(fa[mi], fb[ni], acc[mi][ni]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -445,9 +454,10 @@ extern "C" size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K) {
     return pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
 }
 
-extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t ldx, float* G,
+extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, float* G,
                                  void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(qt_dtype_is16(x_dtype), "qt_xtx_accumulate: x_dtype %d must be QT_BF16 or QT_F16", x_dtype);
     QT_CHECK_ARG(K > 0 && K % 8 == 0, "qt_xtx_accumulate: K=%d must be a positive multiple of 8", K);
     QT_CHECK_ARG(ldx >= K && ldx % 8 == 0, "qt_xtx_accumulate: ldx=%lld must be >= K and a multiple of 8", (long long)ldx);
     QT_CHECK_ARG(n_tokens >= 0, "qt_xtx_accumulate: n_tokens < 0");
@@ -464,7 +474,7 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     }
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
     float* slabs = (float*)ws;
-    __bf16* tail = pl.has_tail ? (__bf16*)(ws + pl.slab_bytes) : nullptr;
+    void* tail = pl.has_tail ? (void*)(ws + pl.slab_bytes) : nullptr;
     int* tile_tab = (int*)(ws + pl.slab_bytes + pl.tail_bytes);
     const int* host_tab = xtx_host_table(K, pl.n_tiles);
     if (!host_tab) {
@@ -476,7 +486,7 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     // with ONE pitch (its per-lane offsets are loop constants), so the staging can stand in for the
     // last tile only when ldx == K; otherwise the call becomes two launches (below).
     XtxParams p;
-    p.X = (const __bf16*)X;
+    p.X = X;
     p.tail = tail;
     p.ldx = ldx;
     p.K = K;
@@ -506,8 +516,9 @@ extern "C" int qt_xtx_accumulate(const void* X, int64_t n_tokens, int K, int64_t
     auto launch = [&](const XtxParams& q, const XtxPlan& ql) -> int {
         const int grid = ql.n_direct + ql.n_rem * ql.s2;
         qt_prof_mark(QT_PROF_XTX, stream);
-        if (q.wrap_units > 0) hipLaunchKernelGGL(xtx_kernel<true>, dim3(grid), dim3(NTHREADS), 0, stream, q);
-        else hipLaunchKernelGGL(xtx_kernel<false>, dim3(grid), dim3(NTHREADS), 0, stream, q);
+        if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false>), dim3(grid), dim3(NTHREADS), 0, stream, q);
+        else if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true>), dim3(grid), dim3(NTHREADS), 0, stream, q);
+        else hipLaunchKernelGGL((xtx_kernel<false, false>), dim3(grid), dim3(NTHREADS), 0, stream, q);
         qt_prof_mark(QT_PROF_XTX, stream);
         QT_LAUNCH_CHECK();
         if (ql.n_rem > 0) {

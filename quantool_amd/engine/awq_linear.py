@@ -50,8 +50,7 @@ def awq_search(weights: Sequence[torch.Tensor], batches: Iterable[torch.Tensor],
     n_tokens = 0
     for xb in batches:
         xb = xb.to(dev)
-        if xb.dtype != torch.bfloat16:
-            xb = xb.to(torch.bfloat16)
+        xb = ops.as_act16(xb)
         ops.xtx_accumulate(xb, G)
         ops.act_stats_accumulate(xb, abs_sum=x_sum)
         n_tokens += xb.numel() // K

@@ -128,7 +128,7 @@ def _first(out):
 
 def _as_bf16_rows(x: torch.Tensor) -> torch.Tensor:
     x = x.reshape(-1, x.shape[-1])
-    return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    return ops.as_act16(x)
 
 
 class _Capture:

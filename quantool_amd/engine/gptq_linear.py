@@ -35,9 +35,9 @@ class HessianAccumulator:
     STAGE_BYTES = 1 << 30      # default token buffer: 1 GiB worth of rows, 4096..65536 tokens
     DIRECT_TOKENS = 16384      # a batch this long is worth its own launch
 
-    def __init__(self, K: int, device, stage_tokens: Optional[int] = None, dtype=torch.bfloat16):
+    def __init__(self, K: int, device, stage_tokens: Optional[int] = None, dtype: Optional[torch.dtype] = None):
         self.K = K
-        self.dtype = dtype
+        self.dtype = dtype          # 16-bit dtype of the staged tokens; None: taken from the first batch
         self._G = torch.zeros((K, K), dtype=torch.float32, device=device)
         self.n = 0
         if stage_tokens is None:
@@ -65,6 +65,9 @@ class HessianAccumulator:
         self.n += int(num_samples)
         if t == 0:
             return
+        if self.dtype is None:
+            # the checkpoint's own dtype (the reference injects none, base.py:222-241); see ops.as_act16
+            self.dtype = X2.dtype if X2.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
         if self.stage_tokens <= 0 or t >= min(self.DIRECT_TOKENS, self.stage_tokens):
             ops.xtx_accumulate(X2 if X2.dtype == self.dtype else X2.to(self.dtype), self._G)
             return
@@ -129,7 +132,7 @@ def gptq_quantize_shared(weights: Sequence[torch.Tensor], acc: HessianAccumulato
                          block_size: int = 128, dampening_frac: float = 0.01,
                          scale_dtype: Optional[torch.dtype] = None,
                          keep: Optional[dict] = None) -> List[GPTQResult]:
-    """Quantise every ``weights[i]`` ([R_i, K], bf16 or fp32) that shares the input behind ``acc``.
+    """Quantise every ``weights[i]`` ([R_i, K], bf16 / fp16 / fp32) that shares the input behind ``acc``.
 
     Follows upstream's ``quantize_weight`` order: observer, optional activation
     ordering, dead columns, damping, factorisation, block sweep; the rows of all weights are
@@ -137,6 +140,11 @@ def gptq_quantize_shared(weights: Sequence[torch.Tensor], acc: HessianAccumulato
     """
     if acc.n <= 0:
         raise ValueError("no calibration samples were accumulated for this Linear")
+    if int(block_size) != 128:
+        # the sweep kernel keeps one 128-column block of U and W in LDS; a different block size changes
+        # which updates are two-rounding rank-1 steps and which are the fma chain of the trailing
+        # product, i.e. the bits -- refuse instead of silently using 128
+        raise ValueError(f"block_size={block_size}: this backend implements upstream's default block_size=128 only")
     K = acc.K
     dev = acc.G.device
     actorder = _normalize_actorder(qargs.actorder)

@@ -86,10 +86,10 @@ class QuantizedLinears:
         return quantization_config(self.weight_config, self.format, self.ignore,
                                    acts.to_config() if acts is not None else None)
 
-    def save_pretrained(self, save_directory, save_compressed: bool = True, **_):
+    def save_pretrained(self, save_directory, save_compressed: bool = True, max_shard_size="5GB", **_):
         from .serialization import save_state
 
-        save_state(self.state_dict(), self.quantization_config(), save_directory)
+        save_state(self.state_dict(), self.quantization_config(), save_directory, max_shard_size=max_shard_size)
 
 
 def _iter_batches(acts) -> Iterable[torch.Tensor]:
@@ -191,12 +191,33 @@ def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = N
             trust_remote_code_model: bool = False, dataset_path: Optional[str] = None,
             calibration_dataloader=None, tokenizer=None, processor=None, splits=None,
             dataset_config_name: Optional[str] = None, text_column: str = "text", pad_to_max_length: bool = False,
+            # upstream names that carry meaning here
+            precision="auto", sequential_targets=None, pipeline: Optional[str] = None,
+            min_tokens_per_module: Optional[float] = None, calibrate_moe_context: bool = False,
+            # upstream names accepted so that quantool routes them here instead of dropping them
+            # (base.py:117-124 matches kwargs against this signature); they concern hub access, logging or
+            # sparsity stages, none of which exists in this backend
+            config_name=None, cache_dir=None, use_auth_token=False, tie_word_embeddings=False,
+            model_revision: str = "main", recipe_args=None, clear_sparse_session: bool = False, stage=None,
+            concatenate_data: bool = False, streaming: bool = False, overwrite_cache: bool = False,
+            preprocessing_num_workers=None, tracing_ignore=None, quantization_aware_calibration: bool = True,
+            log_dir: Optional[str] = None,
             device: Optional[str] = None, seed: int = 42, **unused):
     """Counterpart of ``llmcompressor.oneshot`` for the GPTQ / AWQ / SmoothQuant recipes.
 
-    Keyword names are upstream's, because quantool routes ``quantize(**kwargs)`` entries here by
-    matching them against this signature (``base.py:45-72,117-124``).
+    Keyword names are upstream's ([UPSTREAM-RECALL]), because quantool routes
+    ``quantize(**kwargs)`` entries here by matching them against this signature
+    (``base.py:45-72,117-124``).  ``precision`` selects the dtype a model PATH is loaded in ("auto" =
+    the checkpoint's own); ``sequential_targets`` names the blocks calibrated one after another;
+    ``pipeline`` must be sequential-compatible ("sequential", "independent", "basic" or None: this
+    backend always calibrates block by block).
     """
+    if pipeline not in (None, "sequential", "independent", "basic", "datafree"):
+        raise ValueError(f"pipeline={pipeline!r}: expected 'sequential', 'independent', 'basic' or None")
+    ignored = {k: v for k, v in dict(config_name=config_name, cache_dir=cache_dir, recipe_args=recipe_args, stage=stage,
+                                     log_dir=log_dir, tracing_ignore=tracing_ignore).items() if v not in (None, False)}
+    if ignored or unused:
+        logger.info(f"oneshot: arguments without effect in this backend: {sorted(ignored) + sorted(unused)}")
     if recipe is None:
         raise ValueError("oneshot requires a recipe")
     from ..hip import _lib
@@ -215,7 +236,8 @@ def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = N
         out = oneshot_module(model, dataset, recipe, dev, num_calibration_samples=num_calibration_samples,
                              max_seq_length=max_seq_length, shuffle=shuffle_calibration_samples, tokenizer=tokenizer,
                              dataloader=calibration_dataloader, dataset_path=dataset_path, text_column=text_column,
-                             trust_remote_code=trust_remote_code_model, seed=seed)
+                             trust_remote_code=trust_remote_code_model, seed=seed, precision=precision,
+                             sequential_targets=sequential_targets)
     if output_dir:
         Path(output_dir).mkdir(parents=True, exist_ok=True)
         out.save_pretrained(str(output_dir), save_compressed=save_compressed)

@@ -29,16 +29,95 @@ class _StopForward(Exception):
     pass
 
 
-def find_decoder_layers(model: nn.Module) -> nn.ModuleList:
-    """The longest ModuleList of identical-class blocks (model.model.layers, model.model.decoder.layers, ...)."""
-    best = None
-    for _, m in model.named_modules():
-        if isinstance(m, nn.ModuleList) and len(m) > 0 and len({type(x) for x in m}) == 1:
-            if best is None or len(m) > len(best):
-                best = m
-    if best is None:
-        raise ValueError("could not locate the decoder layers (no homogeneous nn.ModuleList found)")
-    return best
+#: Test hook: when set to a dict, every input group's stage boundaries (factor U, permutation, dead
+#: mask -- ``gptq_quantize_shared(keep=...)``) are stored under its leader's module name, so a parity
+#: test can hand the very same factor to the oracle.  None in production (U is K x K fp32 per group).
+DEBUG_KEEP: Optional[dict] = None
+
+
+def find_decoder_layers(model: nn.Module, sequential_targets=None) -> List[nn.Module]:
+    """The blocks calibrated one after another.
+
+    ``sequential_targets`` (forwarded by the reference plugin, ``gptq/gptq.py:82-84``; upstream: class
+    names such as ``"LlamaDecoderLayer"`` or module names) wins when given.  Otherwise the OUTERMOST
+    homogeneous ``nn.ModuleList`` is taken (``model.model.layers``, ``model.model.decoder.layers``):
+    outermost, not longest -- a sparse-MoE layer holds a ModuleList of experts that can outnumber
+    the decoder layers."""
+    if sequential_targets:
+        targets = [sequential_targets] if isinstance(sequential_targets, str) else list(sequential_targets)
+        hits = [m for n, m in model.named_modules() if type(m).__name__ in targets or n in targets]
+        # a target nested inside another hit is part of that hit
+        inner = {id(c) for m in hits for c in m.modules() if c is not m}
+        hits = [m for m in hits if id(m) not in inner]
+        if not hits:
+            raise ValueError(f"sequential_targets={targets} matches no module (class names or module names expected)")
+        return hits
+    lists = [(n, m) for n, m in model.named_modules()
+             if isinstance(m, nn.ModuleList) and len(m) > 0 and len({type(x) for x in m}) == 1]
+    outer = [(n, m) for n, m in lists if not any(n.startswith(pn + ".") for pn, _ in lists if pn != n)]
+    if not outer:
+        raise ValueError("could not locate the decoder layers (no homogeneous nn.ModuleList found); "
+                         "pass sequential_targets")
+    return list(max(outer, key=lambda nm: len(nm[1]))[1])
+
+
+class _UnfusedExperts(nn.Module):
+    """Stand-in for a fused sparse-MoE expert bank (transformers >= 5: ``gate_up_proj [E, 2I, H]`` and
+    ``down_proj [E, H, I]`` as 3-d parameters): every expert's two matrices become ``nn.Linear``
+    modules whose weights are VIEWS of the fused parameters, so the calibration hooks see each
+    expert's routed tokens and the quantised weights land in the original storage.  The forward is
+    the fused module's own routing loop with the two ``F.linear`` calls replaced by the Linears."""
+
+    def __init__(self, fused: nn.Module):
+        super().__init__()
+        gu, dn = fused.gate_up_proj, fused.down_proj
+        self.num_experts = int(gu.shape[0])
+        self.act_fn = fused.act_fn
+        self.experts = nn.ModuleList()
+        for e in range(self.num_experts):
+            blk = nn.Module()
+            blk.gate_up_proj = nn.Linear(gu.shape[2], gu.shape[1], bias=False, device="meta")
+            blk.down_proj = nn.Linear(dn.shape[2], dn.shape[1], bias=False, device="meta")
+            blk.gate_up_proj.weight = nn.Parameter(gu.data[e], requires_grad=False)
+            blk.down_proj.weight = nn.Parameter(dn.data[e], requires_grad=False)
+            self.experts.append(blk)
+
+    def forward(self, hidden_states, top_k_index, top_k_weights):
+        out = torch.zeros_like(hidden_states)
+        mask = torch.nn.functional.one_hot(top_k_index, num_classes=self.num_experts).permute(2, 1, 0)
+        for e in torch.greater(mask.sum(dim=(-1, -2)), 0).nonzero().flatten().tolist():
+            pos, tok = torch.where(mask[e])
+            gate, up = self.experts[e].gate_up_proj(hidden_states[tok]).chunk(2, dim=-1)
+            y = self.experts[e].down_proj(self.act_fn(gate) * up) * top_k_weights[tok, pos, None]
+            out.index_add_(0, tok, y.to(out.dtype))
+        return out
+
+
+def unfuse_expert_banks(model: nn.Module) -> int:
+    """Replace every fused expert bank by ``_UnfusedExperts``; returns how many were replaced."""
+    n = 0
+    for parent in list(model.modules()):
+        for name, child in list(parent.named_children()):
+            gu, dn = getattr(child, "gate_up_proj", None), getattr(child, "down_proj", None)
+            if (isinstance(gu, nn.Parameter) and isinstance(dn, nn.Parameter) and gu.dim() == 3 and dn.dim() == 3
+                    and hasattr(child, "act_fn") and not isinstance(child, _UnfusedExperts)):
+                setattr(parent, name, _UnfusedExperts(child))
+                n += 1
+    return n
+
+
+def uncovered_weight_fraction(layer: nn.Module, linears: Dict[str, nn.Module]) -> float:
+    """Share of the layer's >= 2-d parameter elements that no targeted Linear holds."""
+    covered = {id(m.weight) for m in linears.values()}
+    storages = {m.weight.untyped_storage().data_ptr() for m in linears.values()}
+    total = held = 0
+    for p in layer.parameters():
+        if p.dim() < 2:
+            continue
+        total += p.numel()
+        if id(p) in covered or p.untyped_storage().data_ptr() in storages:
+            held += p.numel()
+    return 0.0 if total == 0 else 1.0 - held / total
 
 
 def build_batches(dataset, tokenizer, num_samples: int, max_seq_length: int, shuffle: bool, seed: int,
@@ -109,7 +188,7 @@ def _to_dev(x, dev):
     return x
 
 
-def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = True, **_):
+def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = True, max_shard_size="5GB", **_):
     from .serialization import quantization_config, result_tensors, save_state
 
     results: Dict[str, Any] = getattr(model, "_qt_results", {})
@@ -127,12 +206,13 @@ def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = T
                 state[f"{mod}.{k}"] = v
     base_cfg = model.config.to_dict() if hasattr(model, "config") and hasattr(model.config, "to_dict") else {}
     save_state(state, quantization_config(meta.get("weights", {}), meta.get("format", "pack-quantized"),
-                                          meta.get("ignore", []), meta.get("input_activations")), save_directory, base_cfg)
+                                          meta.get("ignore", []), meta.get("input_activations")), save_directory, base_cfg,
+               max_shard_size=max_shard_size)
 
 
 def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int, max_seq_length: int, shuffle: bool,
                    tokenizer=None, dataloader=None, dataset_path=None, text_column: str = "text",
-                   trust_remote_code: bool = False, seed: int = 42):
+                   trust_remote_code: bool = False, seed: int = 42, precision="auto", sequential_targets=None):
     mods = recipe if isinstance(recipe, (list, tuple)) else [recipe]
     gp = next((m for m in mods if isinstance(m, GPTQModifier)), None)
     sq = next((m for m in mods if isinstance(m, SmoothQuantModifier)), None)
@@ -146,8 +226,13 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
         from transformers import AutoModelForCausalLM, AutoTokenizer
 
         path = str(model)
-        model = AutoModelForCausalLM.from_pretrained(path, torch_dtype=torch.bfloat16,
-                                                     trust_remote_code=trust_remote_code, local_files_only=True)
+        # the checkpoint's own dtype unless the caller says otherwise: the reference passes the model
+        # path through with no dtype (base.py:222-241), upstream's `precision` defaults to "auto"
+        dt = {"auto": "auto", None: "auto", "float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
+              "bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "float32": torch.float32, "fp32": torch.float32,
+              "full": torch.float32}.get(precision if not isinstance(precision, torch.dtype) else None, precision)
+        model = AutoModelForCausalLM.from_pretrained(path, dtype=dt, trust_remote_code=trust_remote_code,
+                                                     local_files_only=True)
         if tokenizer is None:
             try:
                 tokenizer = AutoTokenizer.from_pretrained(path, trust_remote_code=trust_remote_code,
@@ -165,7 +250,11 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
         raise ValueError("no calibration batches")
     model.eval()
     model.to(dev)
-    layers = find_decoder_layers(model)
+    n_banks = unfuse_expert_banks(model)
+    if n_banks:
+        logger.info(f"unfused {n_banks} sparse-MoE expert bank(s) into per-expert Linears")
+    seq_targets = sequential_targets or getattr(qm, "sequential_targets", None)
+    layers = find_decoder_layers(model, seq_targets)
     qargs = qm.weight_args()
 
     # ---- inputs of the first decoder layer -------------------------------------------------------
@@ -197,8 +286,13 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 continue
             linears = {f"{lname}.{n}" if n else lname: m for n, m in layer.named_modules()
                        if isinstance(m, nn.Linear) and gp.wants(f"{lname}.{n}", m)}
+            miss = uncovered_weight_fraction(layer, linears)
+            if miss > 0.10:
+                logger.warning(f"{lname}: {100 * miss:.0f}% of the layer's matrix weights are held by no targeted "
+                               "nn.Linear and stay dense (fused or custom-op weights?) although the saved config "
+                               f"declares targets={list(qm.targets)}")
             if sq is not None:
-                _smooth_layer(layer, cache, sq.smoothing_strength, dev)
+                _smooth_layer(layer, cache, sq.smoothing_strength, dev, sq.mappings, lname)
             # discovery pass on batch 0: which Linears read the same tensor.  The input tensors are
             # kept alive until the grouping is done: a freed activation's address can be handed to
             # a later, unrelated tensor of the same shape, and pointer equality would then lie.
@@ -230,8 +324,24 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
 
             def quantize_group(lead, names):
                 ws = [linears[n].weight.data for n in names]
+                if accs[lead].n == 0:
+                    # e.g. a sparse-MoE expert no calibration token was routed to.  Upstream would sweep
+                    # with an all-zero Hessian (every column "dead", weights zeroed); keep the weights
+                    # and round to nearest instead, loudly.
+                    logger.warning(f"{names}: no calibration token reached this input; falling back to "
+                                   "round-to-nearest for these Linears")
+                    from .awq_linear import rtn_finalize
+
+                    for n, w in zip(names, ws):
+                        r = rtn_finalize(w, qargs)
+                        linears[n].weight.data.copy_(r.dequantized(linears[n].weight.dtype))
+                        results[n] = r
+                    return
+                keep = {} if DEBUG_KEEP is not None else None
                 res = gptq_quantize_shared(ws, accs[lead], qargs, block_size=gp.block_size,
-                                           dampening_frac=gp.dampening_frac)
+                                           dampening_frac=gp.dampening_frac, keep=keep)
+                if keep is not None:
+                    DEBUG_KEEP[lead] = dict(keep, names=list(names), n=accs[lead].n, G=accs[lead].G.clone())
                 for n, r in zip(names, res):
                     linears[n].weight.data.copy_(r.dequantized(linears[n].weight.dtype))
                     results[n] = r
@@ -260,13 +370,36 @@ def _advance(layer: nn.Module, cache):
     return new_cache
 
 
-def _smooth_layer(layer: nn.Module, cache, alpha: float, dev) -> None:
-    """SmoothQuant pre-pass with the default decoder mappings: each norm followed by
-    Linears that read its output ({q,k,v} <- input norm, {gate,up} / fc1 <- post-attention norm)."""
+def _smooth_layer(layer: nn.Module, cache, alpha: float, dev, mappings=None, layer_name: str = "") -> None:
+    """SmoothQuant pre-pass.  Default: each norm followed by the Linears that read its
+    output ({q,k,v} <- input norm, {gate,up} / fc1 <- post-attention norm), discovered from tensor
+    identity.  ``SmoothQuantModifier.mappings`` (upstream's ``[[balance patterns], smooth pattern]``
+    pairs, or ``[smooth, [balance...]]`` / dicts as the AWQ resolver takes) restricts it to those."""
     from .smoothquant import ChannelMinMax, apply_smoothing, smoothquant_scales
 
     norms = {n: m for n, m in layer.named_modules()
              if "norm" in type(m).__name__.lower() and getattr(m, "weight", None) is not None and m.weight.dim() == 1}
+    explicit = None
+    if mappings:
+        from .awq_module import _pattern_hits
+
+        explicit = {}
+        named = {n: m for n, m in layer.named_modules()}
+        for mp in mappings:
+            if isinstance(mp, dict):
+                smooth_pat, bal_pats = mp["smooth_layer"] if "smooth_layer" in mp else mp["smooth_layers"], mp["balance_layers"]
+            elif isinstance(mp[0], (list, tuple)):      # upstream SmoothQuant order: [[balance...], smooth]
+                bal_pats, smooth_pat = mp[0], mp[1]
+            else:
+                smooth_pat, bal_pats = mp[0], mp[1]
+            bal_pats = [bal_pats] if isinstance(bal_pats, str) else list(bal_pats)
+            full = lambda n: f"{layer_name}.{n}" if layer_name and n else (layer_name or n)
+            hits = [n for n in named if n and _pattern_hits(str(smooth_pat), full(n)) and getattr(named[n], "weight", None) is not None
+                    and named[n].weight.dim() == 1]
+            lins = [named[n] for n in named if isinstance(named[n], nn.Linear) and any(_pattern_hits(str(p), full(n)) for p in bal_pats)]
+            if len(hits) == 1 and lins:
+                explicit[hits[0]] = lins
+        norms = {n: m for n, m in layer.named_modules() if n in explicit}
     if not norms:
         return
     stats: Dict[str, ChannelMinMax] = {}
@@ -298,7 +431,7 @@ def _smooth_layer(layer: nn.Module, cache, alpha: float, dev) -> None:
         hk.remove()
     out_ref.clear()
     for n, norm in norms.items():
-        lins = consumers[n]
+        lins = explicit[n] if explicit is not None else consumers[n]
         if not lins or n not in stats:
             continue
         s = smoothquant_scales(stats[n], [l.weight.data for l in lins], alpha)

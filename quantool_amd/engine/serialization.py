@@ -10,7 +10,7 @@ from __future__ import annotations
 import json
 import os
 from pathlib import Path
-from typing import Dict
+from typing import Dict, List
 
 import torch
 
@@ -50,14 +50,73 @@ def quantization_config(weight_config: dict, fmt: str, ignore, input_activations
     }
 
 
-def save_state(state: Dict[str, torch.Tensor], qconfig: dict, save_directory, base_config: dict = None) -> None:
+def _parse_size(x) -> int:
+    if isinstance(x, (int, float)):
+        return int(x)
+    t = str(x).strip().upper()
+    for suf, mul in (("GIB", 2 ** 30), ("MIB", 2 ** 20), ("KIB", 2 ** 10), ("GB", 10 ** 9), ("MB", 10 ** 6), ("KB", 10 ** 3)):
+        if t.endswith(suf):
+            return int(float(t[: -len(suf)]) * mul)
+    return int(t)
+
+
+def plan_shards(sizes: Dict[str, int], max_shard_size) -> List[List[str]]:
+    """Greedy split in key order, as ``save_pretrained`` shards a state_dict: a tensor never straddles
+    two files; a single tensor larger than the limit gets a file of its own."""
+    limit = _parse_size(max_shard_size)
+    shards: List[List[str]] = [[]]
+    used = 0
+    for name, nbytes in sizes.items():
+        if shards[-1] and used + nbytes > limit:
+            shards.append([])
+            used = 0
+        shards[-1].append(name)
+        used += nbytes
+    return shards
+
+
+def save_state(state: Dict[str, torch.Tensor], qconfig: dict, save_directory, base_config: dict = None,
+               max_shard_size="5GB") -> None:
+    """One ``model.safetensors`` when the state fits ``max_shard_size`` (``save_pretrained``'s default
+    5GB), else ``model-0000i-of-0000n.safetensors`` files plus ``model.safetensors.index.json``
+    (``{"metadata": {"total_size": bytes}, "weight_map": {tensor name: file}}``) -- a Llama-3-70B
+    W4A16 state is ~35 GB.  Tensors are moved to the host one shard at a time."""
     from safetensors.torch import save_file
 
     dest = Path(save_directory)
     dest.mkdir(parents=True, exist_ok=True)
-    cpu_state = {k: v.detach().to("cpu").contiguous() for k, v in state.items()}
-    save_file(cpu_state, str(dest / "model.safetensors"), metadata={"format": "pt"})
+    sizes = {k: v.numel() * v.element_size() for k, v in state.items()}
+    shards = plan_shards(sizes, max_shard_size)
+    for old in list(dest.glob("model*.safetensors")) + list(dest.glob("model.safetensors.index.json")):
+        old.unlink()
+    if len(shards) == 1:
+        save_file({k: state[k].detach().to("cpu").contiguous() for k in shards[0]}, str(dest / "model.safetensors"),
+                  metadata={"format": "pt"})
+    else:
+        weight_map = {}
+        for i, names in enumerate(shards, 1):
+            fname = f"model-{i:05d}-of-{len(shards):05d}.safetensors"
+            save_file({k: state[k].detach().to("cpu").contiguous() for k in names}, str(dest / fname),
+                      metadata={"format": "pt"})
+            weight_map.update({k: fname for k in names})
+        index = {"metadata": {"total_size": int(sum(sizes.values()))}, "weight_map": weight_map}
+        with open(dest / "model.safetensors.index.json", "w", encoding="utf-8") as fh:
+            json.dump(index, fh, indent=2, sort_keys=True)
     cfg = dict(base_config or {})
     cfg["quantization_config"] = qconfig
     with open(dest / "config.json", "w", encoding="utf-8") as fh:
         json.dump(cfg, fh, indent=2, default=str)
+
+
+def load_state(save_directory) -> Dict[str, torch.Tensor]:
+    """Read back what ``save_state`` wrote (single file or sharded), for tests and tools."""
+    from safetensors.torch import load_file
+
+    dest = Path(save_directory)
+    idx = dest / "model.safetensors.index.json"
+    if not idx.exists():
+        return load_file(str(dest / "model.safetensors"))
+    out: Dict[str, torch.Tensor] = {}
+    for fname in sorted(set(json.loads(idx.read_text())["weight_map"].values())):
+        out.update(load_file(str(dest / fname)))
+    return out

@@ -17,8 +17,7 @@ class ChannelMinMax:
         self.cmax = torch.full((K,), float("-inf"), dtype=torch.float32, device=device)
 
     def add(self, X: torch.Tensor) -> None:
-        if X.dtype != torch.bfloat16:
-            X = X.to(torch.bfloat16)
+        X = ops.as_act16(X)
         ops.act_stats_accumulate(X, cmin=self.cmin, cmax=self.cmax)
 
 

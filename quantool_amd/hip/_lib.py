@@ -25,9 +25,9 @@ SIGNATURES = {
     "qt_version": (c_int, []),
     "qt_last_error": (c_char_p, []),
     "qt_xtx_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "qt_xtx_accumulate": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "qt_xtx_accumulate": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "qt_act_stats_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "qt_act_stats_accumulate": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p,
+    "qt_act_stats_accumulate": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_size_t, c_void_p]),
     "qt_hessian_prepare_workspace_bytes": (c_size_t, [c_int]),
     "qt_hessian_prepare": (c_int, [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import QT_BF16, QT_F32, check, load
+from ._lib import QT_BF16, QT_F16, QT_F32, check, load
 
 _WS_CACHE: dict = {}
 
@@ -29,7 +29,26 @@ def _dtype_code(t: torch.Tensor) -> int:
         return QT_F32
     if t.dtype == torch.bfloat16:
         return QT_BF16
-    raise TypeError(f"unsupported dtype {t.dtype} (fp32 / bf16 only)")
+    if t.dtype == torch.float16:
+        return QT_F16
+    raise TypeError(f"unsupported dtype {t.dtype} (fp32 / bf16 / fp16 only)")
+
+
+def _act16(X: torch.Tensor, name: str) -> int:
+    """Activations cross the boundary in the model's own 16-bit dtype."""
+    if not X.is_cuda:
+        raise ValueError(f"{name} must be a device tensor (no CPU path exists)")
+    if X.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError(f"{name} must be bf16 or fp16, got {X.dtype}")
+    return QT_BF16 if X.dtype == torch.bfloat16 else QT_F16
+
+
+def as_act16(X: torch.Tensor) -> torch.Tensor:
+    """Activations as the kernels take them: the model's own 16-bit dtype, untouched.  Upstream
+    accumulates ``inp.float()``; bf16 and fp16 widen exactly, so nothing is lost.  fp32
+    activations (an fp32 checkpoint) are the one case that is narrowed: they are rounded to bf16
+    (range over mantissa: an fp16 cast could overflow on outlier channels) -- DESIGN.md section 2."""
+    return X if X.dtype in (torch.bfloat16, torch.float16) else X.to(torch.bfloat16)
 
 
 def _req(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None):
@@ -58,9 +77,9 @@ def release_workspaces() -> None:
 
 # ---- a7 -----------------------------------------------------------------------------------
 def xtx_accumulate(X: torch.Tensor, G: torch.Tensor) -> None:
-    """G[K,K] fp32 (lower triangle) += X^T X for X[..., K] bf16 (leading dims flattened)."""
+    """G[K,K] fp32 (lower triangle) += X^T X for X[..., K] bf16 / fp16 (leading dims flattened)."""
     lib = load()
-    _req(X, torch.bfloat16, "X")
+    xdt = _act16(X, "X")
     _req(G, torch.float32, "G", 2)
     K = G.shape[0]
     if G.shape[1] != K or not G.is_contiguous():
@@ -76,7 +95,7 @@ def xtx_accumulate(X: torch.Tensor, G: torch.Tensor) -> None:
     ldx = X2.stride(0) if n > 1 else K
     nbytes = lib.qt_xtx_workspace_bytes(n, K)
     ws = workspace(nbytes, X.device, "xtx")
-    check("qt_xtx_accumulate", lib.qt_xtx_accumulate(X2.data_ptr(), n, K, ldx, G.data_ptr(), ws.data_ptr(),
+    check("qt_xtx_accumulate", lib.qt_xtx_accumulate(X2.data_ptr(), xdt, n, K, ldx, G.data_ptr(), ws.data_ptr(),
                                                      ws.numel(), _stream()))
 
 
@@ -84,7 +103,7 @@ def xtx_accumulate(X: torch.Tensor, G: torch.Tensor) -> None:
 def act_stats_accumulate(X: torch.Tensor, abs_sum: Optional[torch.Tensor] = None,
                          cmin: Optional[torch.Tensor] = None, cmax: Optional[torch.Tensor] = None) -> None:
     lib = load()
-    _req(X, torch.bfloat16, "X")
+    xdt = _act16(X, "X")
     K = X.shape[-1]
     X2 = X.reshape(-1, K)
     if X2.stride(1) != 1:
@@ -100,7 +119,7 @@ def act_stats_accumulate(X: torch.Tensor, abs_sum: Optional[torch.Tensor] = None
     ldx = X2.stride(0) if n > 1 else K
     ws = workspace(lib.qt_act_stats_workspace_bytes(n, K), X.device, "stats")
     check("qt_act_stats_accumulate", lib.qt_act_stats_accumulate(
-        X2.data_ptr(), n, K, ldx, _ptr(abs_sum), _ptr(cmin), _ptr(cmax), ws.data_ptr(), ws.numel(), _stream()))
+        X2.data_ptr(), xdt, n, K, ldx, _ptr(abs_sum), _ptr(cmin), _ptr(cmax), ws.data_ptr(), ws.numel(), _stream()))
 
 
 # ---- a8 / a9 ------------------------------------------------------------------------------

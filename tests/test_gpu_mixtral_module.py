@@ -1,0 +1,77 @@
+"""Config 5 through the nn.Module path: a tiny random-init Mixtral (transformers >= 5 keeps the experts
+as fused 3-d parameters ``gate_up_proj [E, 2I, H]`` / ``down_proj [E, H, I]``, which a Linear-only walk
+would silently leave dense).  The driver unfuses every expert bank into per-expert Linears that
+view the fused storage, so each expert is calibrated on its own routed tokens."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_mixtral(dev):
+    from transformers import MixtralConfig, MixtralForCausalLM
+
+    cfg = MixtralConfig(hidden_size=256, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                        num_key_value_heads=2, num_local_experts=4, num_experts_per_tok=2, vocab_size=512,
+                        max_position_embeddings=128, tie_word_embeddings=False)
+    torch.manual_seed(0)
+    return MixtralForCausalLM(cfg).to(torch.bfloat16).to(dev).eval()
+
+
+def test_unfused_experts_keep_the_function_and_the_storage(dev):
+    from quantool_amd.engine.sequential import find_decoder_layers, uncovered_weight_fraction, unfuse_expert_banks
+
+    m = _tiny_mixtral(dev)
+    x = torch.randint(0, 512, (1, 24), device=dev)
+    with torch.no_grad():
+        y0 = m(input_ids=x).logits.clone()
+    fused = m.model.layers[0].mlp.experts.gate_up_proj
+    assert unfuse_expert_banks(m) == 2
+    with torch.no_grad():
+        y1 = m(input_ids=x).logits
+    assert torch.equal(y0, y1)
+    lin = m.model.layers[0].mlp.experts.experts[1].gate_up_proj
+    assert lin.weight.untyped_storage().data_ptr() == fused.untyped_storage().data_ptr()     # a view, not a copy
+    layers = find_decoder_layers(m)
+    assert len(layers) == 2 and type(layers[0]).__name__ == "MixtralDecoderLayer"        # not the 4-expert list
+    linears = {n: mod for n, mod in layers[0].named_modules() if isinstance(mod, torch.nn.Linear)}
+    assert len(linears) == 4 + 2 * 4 and uncovered_weight_fraction(layers[0], linears) < 0.02   # the router only
+
+
+def test_gptq_plugin_quantises_every_expert_on_its_routed_tokens(dev, oracle, tmp_path, monkeypatch):
+    import quantool_amd.methods  # noqa: F401
+    from quantool_amd.core import QuantizerRegistry
+    from quantool_amd.engine import sequential
+    from quantool_amd.engine.sequential import unfuse_expert_banks
+
+    from tests.util import hook_inputs, oracle_group
+
+    monkeypatch.chdir(tmp_path)
+    model, ref = _tiny_mixtral(dev), _tiny_mixtral(dev)
+    unfuse_expert_banks(ref)
+    g = torch.Generator().manual_seed(3)
+    data = [{"input_ids": torch.randint(0, 512, (64,), generator=g)} for _ in range(8)]
+    monkeypatch.setattr(sequential, "DEBUG_KEEP", {})
+    q = QuantizerRegistry.create("gptq", model_id="synthetic/tiny-mixtral")
+    q.quantize(model=model, level="W4A16", dataset=data, num_calibration_samples=8, max_seq_length=64,
+               shuffle_calibration_samples=False)
+    torch.cuda.synchronize()
+    res, keep = model._qt_results, sequential.DEBUG_KEEP
+    assert len(res) == 2 * (4 + 2 * 4)
+    pre = "model.layers.0.mlp.experts.experts."
+    counts = []
+    for e in range(4):
+        for which in ("gate_up_proj", "down_proj"):
+            name = f"{pre}{e}.{which}"
+            k = keep[name]
+            mod = ref.model.layers[0].mlp.experts.experts[e].get_submodule(which)
+            acts = hook_inputs(ref, mod, data, dev)
+            assert sum(a.shape[0] for a in acts) > 0
+            counts.append(sum(a.shape[0] for a in acts))
+            (o,) = oracle_group(oracle, acts, [mod.weight.data], k)
+            np.testing.assert_array_equal(res[name].weight_packed.cpu().numpy(), oracle.pack_int4(o["q"]), err_msg=name)
+    assert len(set(counts)) > 1                      # ragged: the experts saw different token counts
+    # the fused parameter now holds the dequantised experts
+    fused = model.model.layers[0].mlp.experts.experts[2].gate_up_proj.weight
+    assert torch.equal(fused.data, res[f"{pre}2.gate_up_proj"].dequantized(torch.bfloat16))

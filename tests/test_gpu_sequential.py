@@ -22,9 +22,9 @@ def _tiny_llama(dev):
 def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
     import quantool_amd.methods  # noqa: F401
     from quantool_amd.core import QuantizerRegistry
-    from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
-    from quantool_amd.engine.schemes import QuantArgs
     from safetensors.torch import load_file
+
+    from tests.util import hook_inputs, oracle_group
 
     monkeypatch.chdir(tmp_path)
     model = _tiny_llama(dev)
@@ -32,17 +32,9 @@ def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
     g = torch.Generator().manual_seed(1)
     data = [{"input_ids": torch.randint(0, 512, (48,), generator=g)} for _ in range(8)]
 
-    # expected layer-0 attention-input group, computed directly on the hooked activations
-    acc = HessianAccumulator(256, dev)
-    l0 = ref.model.layers[0]
-    hk = l0.self_attn.q_proj.register_forward_pre_hook(lambda m, a: acc.add(a[0]))
-    with torch.no_grad():
-        for row in data:
-            ref(input_ids=row["input_ids"].reshape(1, -1).to(dev), use_cache=False)
-    hk.remove()
-    want = gptq_quantize_shared([l0.self_attn.q_proj.weight.data, l0.self_attn.k_proj.weight.data,
-                                 l0.self_attn.v_proj.weight.data], acc, QuantArgs(actorder="static"))
+    from quantool_amd.engine import sequential
 
+    monkeypatch.setattr(sequential, "DEBUG_KEEP", {})
     q = QuantizerRegistry.create("gptq", model_id="synthetic/tiny-llama")
     out = q.quantize(model=model, level="W4A16", dataset=data, num_calibration_samples=8, max_seq_length=64,
                      shuffle_calibration_samples=False)
@@ -52,25 +44,28 @@ def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
     for lname in ("q_proj", "k_proj", "v_proj"):
         key = f"model.layers.0.self_attn.{lname}"
         assert f"{key}.weight" not in sd and f"{key}.weight_packed" in sd
-    assert torch.equal(sd["model.layers.0.self_attn.q_proj.weight_packed"], want[0].weight_packed.cpu())
-    assert torch.equal(sd["model.layers.0.self_attn.k_proj.weight_packed"], want[1].weight_packed.cpu())
+    # The driver against the ORACLE on what a plain hook sees (not against the HIP path itself): the
+    # q/k/v group shares one Hessian; o_proj reads a different tensor of the same shape as the hidden
+    # state and must have got its own.  Within a layer every Linear is calibrated on the activations of
+    # the layer with its ORIGINAL weights (hooks pass first, quantisation after: SURVEY A.1 (i)-(ii)).
+    keep = sequential.DEBUG_KEEP
+    l0 = ref.model.layers[0]
+    pre = "model.layers.0."
+    by_members = {frozenset(v["names"]): v for key, v in keep.items() if key.startswith(pre)}
+    assert sorted(map(len, by_members)) == [1, 1, 2, 3]            # q/k/v, o, gate/up, down
+    for members in (["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"], ["self_attn.o_proj"],
+                    ["mlp.gate_proj", "mlp.up_proj"], ["mlp.down_proj"]):
+        k = by_members[frozenset(pre + m for m in members)]
+        sub = [n[len(pre):] for n in k["names"]]
+        acts = hook_inputs(ref, l0.get_submodule(sub[0]), data, dev)
+        outs = oracle_group(oracle, acts, [l0.get_submodule(m).weight.data for m in sub], k)
+        for n, o in zip(k["names"], outs):
+            np.testing.assert_array_equal(sd[f"{n}.weight_packed"].numpy(), oracle.pack_int4(o["q"]), err_msg=n)
+            np.testing.assert_array_equal(model._qt_results[n].scale_f32.cpu().numpy(), o["scale"], err_msg=n)
     assert "lm_head.weight" in sd and "lm_head.weight_packed" not in sd          # ignored
     assert "model.embed_tokens.weight" in sd
     n_q = sum(1 for k in sd if k.endswith("weight_packed"))
     assert n_q == 2 * 7
-    # o_proj reads a different tensor of the same shape as the hidden state: it must have got its
-    # own Hessian.  Within a layer every Linear is calibrated on the activations of the layer with
-    # its ORIGINAL weights (hooks pass first, quantisation after: SURVEY A.1 (i)-(ii)).
-    acc_o = HessianAccumulator(256, dev)
-    ref2 = _tiny_llama(dev)
-    hk2 = ref2.model.layers[0].self_attn.o_proj.register_forward_pre_hook(lambda m, a: acc_o.add(a[0]))
-    with torch.no_grad():
-        for row in data:
-            ref2(input_ids=row["input_ids"].reshape(1, -1).to(dev), use_cache=False)
-    hk2.remove()
-    want_o = gptq_quantize_shared([ref2.model.layers[0].self_attn.o_proj.weight.data], acc_o,
-                                  QuantArgs(actorder="static"))[0]
-    assert torch.equal(sd["model.layers.0.self_attn.o_proj.weight_packed"], want_o.weight_packed.cpu())
     # weights were replaced by dequantised values on the int4 grid
     w = model.model.layers[1].mlp.down_proj.weight.data.float().cpu().numpy()
     r = model._qt_results["model.layers.1.mlp.down_proj"]
