@@ -30,7 +30,9 @@ def test_unfused_experts_keep_the_function_and_the_storage(dev):
     assert unfuse_expert_banks(m) == 2
     with torch.no_grad():
         y1 = m(input_ids=x).logits
-    assert torch.equal(y0, y1)
+    # same routing, same weights; the fused module may run its experts through another GEMM kernel
+    # (grouped / batched), so bf16 logits agree to rounding, not bit for bit (they do on the CPU in fp32)
+    assert torch.allclose(y0.float(), y1.float(), rtol=3e-2, atol=3e-2)
     lin = m.model.layers[0].mlp.experts.experts[1].gate_up_proj
     assert lin.weight.untyped_storage().data_ptr() == fused.untyped_storage().data_ptr()     # a view, not a copy
     layers = find_decoder_layers(m)
