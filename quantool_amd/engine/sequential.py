@@ -305,7 +305,12 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 hk.remove()
             groups: Dict[tuple, List[str]] = {}
             for n in linears:
-                t = seen[n]
+                t = seen.get(n)
+                if t is None:
+                    # not reached by batch 0 (a sparse-MoE expert none of its tokens was routed to):
+                    # sharing cannot be established, so the Linear keeps a Hessian of its own
+                    groups[("solo", n)] = [n]
+                    continue
                 key = (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()))
                 groups.setdefault(key, []).append(n)
             seen.clear()
