@@ -117,16 +117,59 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
     smoothing_scales: Dict[str, torch.Tensor] = {}
     if gp is not None:
         qargs = gp.weight_args()
+        from .sharding import (GatheredResult, allreduce_accumulator, dist_world, gather_state_dict, group_cost,
+                               gptq_quantize_row_split, plan_groups)
         from .streams import GroupStreams
 
-        pool = GroupStreams(device)
+        # One process per GPU (torchrun): every rank is given the same calibration set; whole groups go to
+        # ranks LPT-greedy (partitioning A), a group heavier than a fair share is split over all ranks
+        # (partitioning B: tokens for the Gram sum, rows for the sweep), and rank 0 ends up with the
+        # whole quantised state (north_star: "RCCL ... only to gather the final state_dict").
+        world, rank = dist_world()
+        order = sorted(cal.groups, key=lambda g: (-int(next(iter(g.weights.values())).shape[1]), g.name))
+        if world > 1:
+            def n_tok(g):
+                a = g.activations
+                if isinstance(a, torch.Tensor):
+                    return a.numel() // a.shape[-1]
+                if isinstance(a, (list, tuple)):
+                    return sum(t.numel() // t.shape[-1] for t in a)
+                return 196608     # an iterator cannot be sized without consuming it: the default calibration set
+            costs = [group_cost(int(next(iter(g.weights.values())).shape[1]), n_tok(g),
+                                sum(int(w.shape[0]) for w in g.weights.values())) for g in order]
+            plan = dict(zip((g.name for g in order), plan_groups(costs, world)))
+        else:
+            plan = {g.name: ("A", 0) for g in order}
+
+        def local_batches(g, split: bool):
+            """This rank's calibration batches of a group, with the sample count they stand for."""
+            if not split:
+                for xb in _iter_batches(g.activations):
+                    yield xb, None
+                return
+            a = g.activations
+            if isinstance(a, torch.Tensor) and a.dim() == 3:
+                for i in range(rank, a.shape[0], world):
+                    yield a[i:i + 1], 1
+            elif isinstance(a, torch.Tensor):
+                rows = a.reshape(-1, a.shape[-1])
+                per = (rows.shape[0] + world - 1) // world
+                yield rows[rank * per:(rank + 1) * per], (1 if rank == 0 else 0)
+            else:
+                for i, xb in enumerate(_iter_batches(a)):
+                    if i % world == rank:
+                        yield xb, None
 
         def do_group(g):
+            kind, owner = plan[g.name]
+            if kind == "A" and owner != rank:
+                return
             weights = {n: w.to(device) for n, w in g.weights.items()}
             rescale = None
             if sq is not None and g.smooth_vectors:
                 # SmoothQuant stage of the recipe (SURVEY A.4): every Linear of the group is a balance
-                # layer -- ignored ones included, they read the same rescaled activation
+                # layer -- ignored ones included, they read the same rescaled activation.  (A split group
+                # computes the same scales from the full activations on every rank.)
                 rescale = _smooth_group(g, weights, sq.smoothing_strength, device, smoothed)
                 smoothing_scales[g.name] = rescale
             names = [n for n in weights if n.split(".")[-1] not in gp.ignore and n not in gp.ignore]
@@ -134,21 +177,49 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
                 return
             K = weights[names[0]].shape[1]
             acc = HessianAccumulator(K, device)
-            for xb in _iter_batches(g.activations):
+            for xb, ns in local_batches(g, kind == "B"):
                 xb = xb.to(device)
+                if xb.numel() == 0:
+                    continue
                 if rescale is not None:      # what the smoothed norm now emits: X / s, in the activation dtype
                     xb = ops.scale_columns(xb.reshape(-1, K), rescale, divide=True).reshape(xb.shape)
-                acc.add(xb, num_samples=None)
+                acc.add(xb, num_samples=ns)
+            if kind == "B":
+                allreduce_accumulator(acc)
             if g.num_samples is not None:
                 acc.n = int(g.num_samples)
-            res = gptq_quantize_shared([weights[n] for n in names], acc, qargs,
-                                       block_size=gp.block_size, dampening_frac=gp.dampening_frac)
+            ws = [weights[n] for n in names]
+            if kind == "B":
+                res = gptq_quantize_row_split(ws, acc, qargs, block_size=gp.block_size, dampening_frac=gp.dampening_frac)
+            else:
+                res = gptq_quantize_shared(ws, acc, qargs, block_size=gp.block_size, dampening_frac=gp.dampening_frac)
             results.update(dict(zip(names, res)))
 
-        # one stream per group, largest in_features first (longest chain): see streams.py
-        for g in sorted(cal.groups, key=lambda g: -int(next(iter(g.weights.values())).shape[1])):
-            pool.run(lambda g=g: do_group(g))
-        pool.join()
+        if world > 1:
+            for g in order:          # collectives must be issued in the same order on every rank: one stream
+                do_group(g)
+            from .serialization import result_tensors
+
+            mine = {f"{n}::{k}": v for n, r in results.items() if plan_owner_is(plan, cal, n, rank)
+                    for k, v in result_tensors(r).items()}
+            backend_dev = device if torch.distributed.get_backend() != "gloo" else None
+            merged = gather_state_dict(mine, dst=0, device=backend_dev)
+            if rank == 0:
+                by_lin: Dict[str, dict] = {}
+                for key, t in merged.items():
+                    n, k = key.split("::")
+                    by_lin.setdefault(n, {})[k] = t.to(device)
+                for n, parts in by_lin.items():
+                    if n not in results:
+                        if "weight" in parts:
+                            parts["weight_q"] = parts.pop("weight")
+                        results[n] = GatheredResult(parts, None)
+        else:
+            # one stream per group, largest in_features first (longest chain): see streams.py
+            pool = GroupStreams(device)
+            for g in order:
+                pool.run(lambda g=g: do_group(g))
+            pool.join()
         mod = gp
     else:
         from .awq_linear import awq_quantize_group
@@ -164,6 +235,16 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
         mod = aw
     return QuantizedLinears(results, recipe, mod.scheme, mod.resolved_scheme.format, qargs.to_config(), list(mod.ignore),
                             smoothed, smoothing_scales)
+
+
+def plan_owner_is(plan, cal, lin_name: str, rank: int) -> bool:
+    """True when ``rank`` is the one that sends Linear ``lin_name`` in the final gather: the owner of its
+    group under partitioning A, rank 0 for a split group (every rank holds those)."""
+    for g in cal.groups:
+        if lin_name in g.weights:
+            kind, owner = plan[g.name]
+            return owner == rank if kind == "A" else rank == 0
+    return False
 
 
 def _smooth_group(g: LinearGroup, weights: Dict[str, torch.Tensor], alpha: float, device,
@@ -239,6 +320,9 @@ def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = N
                              trust_remote_code=trust_remote_code_model, seed=seed, precision=precision,
                              sequential_targets=sequential_targets)
     if output_dir:
-        Path(output_dir).mkdir(parents=True, exist_ok=True)
-        out.save_pretrained(str(output_dir), save_compressed=save_compressed)
+        from .sharding import dist_world
+
+        if dist_world()[1] == 0:      # under torchrun rank 0 holds the whole state and is the one that writes
+            Path(output_dir).mkdir(parents=True, exist_ok=True)
+            out.save_pretrained(str(output_dir), save_compressed=save_compressed)
     return out

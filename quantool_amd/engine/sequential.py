@@ -191,6 +191,10 @@ def _to_dev(x, dev):
 def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = True, max_shard_size="5GB", **_):
     from .serialization import quantization_config, result_tensors, save_state
 
+    from .sharding import dist_world
+
+    if dist_world()[1] != 0:
+        return            # under torchrun every rank holds the same quantised model; rank 0 writes it
     results: Dict[str, Any] = getattr(model, "_qt_results", {})
     meta = getattr(model, "_qt_meta", {})
     state: Dict[str, torch.Tensor] = {}
@@ -248,6 +252,17 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                             dataloader)
     if not batches:
         raise ValueError("no calibration batches")
+    # One process per GPU (torchrun): the calibration SAMPLES are split over the ranks (every rank holds
+    # the model and forwards its own share), each input group's Gram sum is all-reduced once per layer,
+    # every rank factorises the same Hessian and sweeps its slice of the rows, and the rows are
+    # all-gathered -- partitioning B of SURVEY 8e for every group, so the replicated models stay equal.
+    from .sharding import allreduce_accumulator, dist_world, gptq_quantize_row_split
+
+    world, rank = dist_world()
+    if world > 1 and aw is None:
+        if len(batches) < world:
+            raise ValueError(f"{len(batches)} calibration samples cannot be split over {world} ranks")
+        batches = batches[rank::world]
     model.eval()
     model.to(dev)
     n_banks = unfuse_expert_banks(model)
@@ -324,11 +339,14 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 layer(*args, **kwargs)
             for hk in hooks:
                 hk.remove()
-            # one stream per input group, largest in_features first (longest chain): see streams.py
-            pool = GroupStreams(dev)
+            # one stream per input group, largest in_features first (longest chain): see streams.py;
+            # under torchrun one stream, so that every rank issues its collectives in the same order
+            pool = GroupStreams(dev) if world == 1 else None
 
             def quantize_group(lead, names):
                 ws = [linears[n].weight.data for n in names]
+                if world > 1:
+                    allreduce_accumulator(accs[lead])
                 if accs[lead].n == 0:
                     # e.g. a sparse-MoE expert no calibration token was routed to.  Upstream would sweep
                     # with an all-zero Hessian (every column "dead", weights zeroed); keep the weights
@@ -343,17 +361,25 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                         results[n] = r
                     return
                 keep = {} if DEBUG_KEEP is not None else None
-                res = gptq_quantize_shared(ws, accs[lead], qargs, block_size=gp.block_size,
-                                           dampening_frac=gp.dampening_frac, keep=keep)
-                if keep is not None:
+                if world > 1:
+                    res = gptq_quantize_row_split(ws, accs[lead], qargs, block_size=gp.block_size,
+                                                  dampening_frac=gp.dampening_frac, with_dequantized=True)
+                else:
+                    res = gptq_quantize_shared(ws, accs[lead], qargs, block_size=gp.block_size,
+                                               dampening_frac=gp.dampening_frac, keep=keep)
+                if keep is not None and world == 1:
                     DEBUG_KEEP[lead] = dict(keep, names=list(names), n=accs[lead].n, G=accs[lead].G.clone())
                 for n, r in zip(names, res):
                     linears[n].weight.data.copy_(r.dequantized(linears[n].weight.dtype))
                     results[n] = r
 
-            for lead, names in sorted(leaders.items(), key=lambda kv: -linears[kv[0]].in_features):
-                pool.run(lambda lead=lead, names=names: quantize_group(lead, names))
-            pool.join()
+            for lead, names in sorted(leaders.items(), key=lambda kv: (-linears[kv[0]].in_features, kv[0])):
+                if pool is not None:
+                    pool.run(lambda lead=lead, names=names: quantize_group(lead, names))
+                else:
+                    quantize_group(lead, names)
+            if pool is not None:
+                pool.join()
             accs.clear()
             cache = _advance(layer, cache)
             logger.info(f"quantized {lname}: {len(linears)} Linears in {len(leaders)} input groups")
@@ -435,6 +461,16 @@ def _smooth_layer(layer: nn.Module, cache, alpha: float, dev, mappings=None, lay
     for hk in hooks:
         hk.remove()
     out_ref.clear()
+    from .sharding import dist_world
+
+    if dist_world()[0] > 1:
+        import torch.distributed as dist
+
+        from .sharding import allreduce_inplace
+
+        for n in sorted(stats):       # the calibration samples are split over the ranks: global min / max
+            allreduce_inplace(stats[n].cmin, dist.ReduceOp.MIN)
+            allreduce_inplace(stats[n].cmax, dist.ReduceOp.MAX)
     for n, norm in norms.items():
         lins = explicit[n] if explicit is not None else consumers[n]
         if not lins or n not in stats:

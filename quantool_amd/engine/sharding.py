@@ -12,7 +12,7 @@ data-path collective.  The only exchange is the gather of the packed state to ra
 from __future__ import annotations
 
 import io
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -130,6 +130,16 @@ def _comm(t: torch.Tensor, group=None) -> torch.Tensor:
     return t.cpu() if dist.get_backend(group) == "gloo" and t.is_cuda else t
 
 
+def allreduce_inplace(t: torch.Tensor, op=None, group=None) -> None:
+    """``dist.all_reduce`` on a device tensor whatever the backend (gloo: through the host)."""
+    import torch.distributed as dist
+
+    c = _comm(t, group)
+    dist.all_reduce(c, op=op if op is not None else dist.ReduceOp.SUM, group=group)
+    if c is not t:
+        t.copy_(c)
+
+
 def row_slices(rows: int, world: int) -> List[Tuple[int, int]]:
     """Contiguous, balanced [begin, end) row ranges, one per rank (the first ``rows % world`` ranks
     take one extra row; a rank may get none when rows < world)."""
@@ -142,41 +152,97 @@ def row_slices(rows: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def gptq_quantize_token_split(weights: Sequence[torch.Tensor], local_batches, qargs, *, group=None,
-                              block_size: int = 128, dampening_frac: float = 0.01,
-                              num_local_samples: int = None):
-    """Quantise the Linears that share one input when the calibration TOKENS of that input are
-    spread over the ranks -- the shape that balances a decoder layer whose down_proj alone is two
-    thirds of the work, and Llama-3-70B's K = 28672 group (SURVEY 8e, partitioning B):
-
-    1. every rank accumulates X^T X over its own batches                      (no communication)
-    2. one all-reduce of the K x K partial Gram sums and of the sample counts (the exchange step)
-    3. every rank factorises the same Hessian -- replicated: 2/3 K^3 flop is cheaper than moving
-       the K^2 factor -- and sweeps only ITS rows of every weight (rows are independent given U)
-    4. one all-gather of the packed rows and their scales                     (the gather step)
-
-    Returns, on every rank, {"weight_packed": [R, K/8] int32 (or "weight_q" int8 for 8-bit),
-    "weight_scale", optional "weight_zero_point" / "weight_g_idx"} per weight, full height.
-    Results are bit-identical to a single-rank run on a Gram matrix summed in the same order
-    (for two ranks: G0 + G1), which is what ``tests/test_gpu_token_split.py`` checks."""
+def dist_world(group=None) -> Tuple[int, int]:
+    """(world size, rank) of the default process group, (1, 0) when torch.distributed is not in use."""
     import torch.distributed as dist
 
-    from .gptq_linear import HessianAccumulator, gptq_quantize_shared
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
 
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    K = int(weights[0].shape[1])
-    dev = weights[0].device
-    acc = HessianAccumulator(K, dev)
-    for xb in local_batches:
-        acc.add(xb.to(dev))
-    if num_local_samples is not None:
-        acc.n = int(num_local_samples)
+
+def plan_groups(costs: Sequence[float], world: int) -> List[Tuple[str, int]]:
+    """How a layer's Linear groups are spread over ``world`` ranks.  A group whose cost alone
+    exceeds a fair share (total / world) is SPLIT over all ranks (partitioning B: tokens for the Gram
+    sum, rows for the sweep) -- down_proj is two thirds of a Llama layer, 70B's K = 28672 group more;
+    the rest are whole units assigned LPT-greedy (partitioning A) on top of the split groups' even load.
+    Returns ("B", -1) or ("A", owner) per group; deterministic, so every rank computes the same plan."""
+    if world <= 1:
+        return [("A", 0)] * len(costs)
+    share = sum(costs) / world
+    split = [c > share for c in costs]
+    rest = [i for i, sp in enumerate(split) if not sp]
+    owners = lpt_assign([costs[i] for i in rest], world)
+    plan: List[Tuple[str, int]] = [("B", -1)] * len(costs)
+    for i, o in zip(rest, owners):
+        plan[i] = ("A", o)
+    return plan
+
+
+def allreduce_accumulator(acc, group=None) -> None:
+    """Sum a ``HessianAccumulator`` over the ranks in place (lower-triangle bands of G and n)."""
     g = _comm(acc.G, group)
     n_total = allreduce_gram(g, acc.n, group)
     if g is not acc.G:
         acc.G.copy_(g)
     acc.n = n_total
 
+
+class GatheredResult:
+    """Full-height outputs of one Linear whose rows were swept on several ranks: the state_dict
+    entries of a ``GPTQResult`` plus, when asked for, the dequantised weight in the model dtype."""
+
+    def __init__(self, parts: dict, w_dq: Optional[torch.Tensor]):
+        self.weight_packed = parts.get("weight_packed")
+        self.weight_q = parts.get("weight_q")
+        self.weight_scale = parts["weight_scale"]
+        self.weight_zero_point = parts.get("weight_zero_point")
+        self.weight_g_idx = parts.get("weight_g_idx")
+        self.weight_shape = parts["weight_shape"]
+        self._w_dq = w_dq
+
+    def dequantized(self, dtype=torch.float32) -> torch.Tensor:
+        if self._w_dq is None:
+            raise RuntimeError("dequantised rows were not gathered (gptq_quantize_row_split(with_dequantized=True))")
+        return self._w_dq.to(dtype)
+
+
+def _all_gather_rows(mine_t: Optional[torch.Tensor], slices, rank: int, dev, group):
+    """All-gather a row-split tensor (some ranks may hold no rows).  Returns None when no rank has it."""
+    import torch.distributed as dist
+
+    world = len(slices)
+    metas = [None] * world
+    dist.all_gather_object(metas, None if mine_t is None else
+                           (int(mine_t.shape[1]), str(mine_t.dtype).replace("torch.", "")), group=group)
+    ref = next((m for m in metas if m is not None), None)
+    if ref is None:
+        return None                                    # e.g. symmetric: no zero point anywhere
+    b, e = slices[rank]
+    tallest = max(eb - bb for bb, eb in slices)
+    # all_gather wants equal shapes: every rank sends `tallest` rows, the tail is padding
+    send = torch.zeros((tallest, ref[0]), dtype=getattr(torch, ref[1]), device=dev)
+    if mine_t is not None:
+        send[:e - b] = mine_t
+    send = _comm(send, group)
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(bufs, send, group=group)
+    return torch.cat([buf[:eb - bb] for buf, (bb, eb) in zip(bufs, slices)], 0).to(dev)
+
+
+def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, group=None, block_size: int = 128,
+                            dampening_frac: float = 0.01, with_dequantized: bool = False) -> List[GatheredResult]:
+    """Steps 3-4 of partitioning B on an accumulator that already holds the GLOBAL Gram sum: every rank
+    factorises the same Hessian (replicated: 2/3 K^3 flop is cheaper than moving the K^2 factor), sweeps
+    only its contiguous slice of every weight's rows (rows are independent given U), and the packed
+    rows, scales (and, for the sequential driver's write-back, the dequantised rows) are all-gathered."""
+    import torch.distributed as dist
+
+    from .gptq_linear import gptq_quantize_shared
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    K = int(weights[0].shape[1])
+    dev = weights[0].device
     mine = [row_slices(int(w.shape[0]), world)[rank] for w in weights]
     local = [w[b:e] for w, (b, e) in zip(weights, mine) if e > b]
     res = iter(gptq_quantize_shared(local, acc, qargs, block_size=block_size, dampening_frac=dampening_frac)
@@ -186,24 +252,14 @@ def gptq_quantize_token_split(weights: Sequence[torch.Tensor], local_batches, qa
         r = next(res) if e > b else None
         R = int(w.shape[0])
         slices = row_slices(R, world)
-        tallest = max(eb - bb for bb, eb in slices)
         parts = {}
         for key in ("weight_packed", "weight_q", "weight_scale", "weight_zero_point"):
-            mine_t = getattr(r, key, None) if r is not None else None
-            metas = [None] * world
-            dist.all_gather_object(metas, None if mine_t is None else
-                                   (int(mine_t.shape[1]), str(mine_t.dtype).replace("torch.", "")), group=group)
-            ref = next((m for m in metas if m is not None), None)
-            if ref is None:
-                continue                                   # nobody has this tensor (e.g. symmetric: no zero point)
-            # all_gather wants equal shapes: every rank sends `tallest` rows, the tail is padding
-            send = torch.zeros((tallest, ref[0]), dtype=getattr(torch, ref[1]), device=dev)
-            if mine_t is not None:
-                send[:e - b] = mine_t
-            send = _comm(send, group)
-            bufs = [torch.empty_like(send) for _ in range(world)]
-            dist.all_gather(bufs, send, group=group)
-            parts[key] = torch.cat([buf[:eb - bb] for buf, (bb, eb) in zip(bufs, slices)], 0).to(dev)
+            got = _all_gather_rows(getattr(r, key, None) if r is not None else None, slices, rank, dev, group)
+            if got is not None:
+                parts[key] = got
+        w_dq = None
+        if with_dequantized:
+            w_dq = _all_gather_rows(r.dequantized(w.dtype) if r is not None else None, slices, rank, dev, group)
         if str(qargs.actorder).lower() == "group":
             # the same on every rank that swept rows; ranks without rows get it from the first that did
             g_idx = r.weight_g_idx if r is not None else None
@@ -214,5 +270,42 @@ def gptq_quantize_token_split(weights: Sequence[torch.Tensor], local_batches, qa
                 g_idx = holder[0].to(dev)
             parts["weight_g_idx"] = g_idx
         parts["weight_shape"] = torch.tensor([R, K], dtype=torch.int64)
+        out.append(GatheredResult(parts, w_dq))
+    return out
+
+
+def gptq_quantize_token_split(weights: Sequence[torch.Tensor], local_batches, qargs, *, group=None,
+                              block_size: int = 128, dampening_frac: float = 0.01,
+                              num_local_samples: int = None):
+    """Quantise the Linears that share one input when the calibration TOKENS of that input are
+    spread over the ranks -- the shape that balances a decoder layer whose down_proj alone is two
+    thirds of the work, and Llama-3-70B's K = 28672 group (SURVEY 8e, partitioning B):
+
+    1. every rank accumulates X^T X over its own batches                      (no communication)
+    2. one all-reduce of the partial Gram sums (lower-triangle bands) and of the sample counts
+       (the exchange step)
+    3. every rank factorises the same Hessian and sweeps only ITS rows of every weight
+    4. one all-gather of the packed rows and their scales                     (the gather step)
+
+    Returns, on every rank, {"weight_packed": [R, K/8] int32 (or "weight_q" int8 for 8-bit),
+    "weight_scale", optional "weight_zero_point" / "weight_g_idx"} per weight, full height.
+    Results are bit-identical to a single-rank run on a Gram matrix summed in the same order
+    (for two ranks: G0 + G1), which is what ``tests/test_gpu_token_split.py`` checks."""
+    from .gptq_linear import HessianAccumulator
+
+    K = int(weights[0].shape[1])
+    dev = weights[0].device
+    acc = HessianAccumulator(K, dev)
+    for xb in local_batches:
+        acc.add(xb.to(dev))
+    if num_local_samples is not None:
+        acc.n = int(num_local_samples)
+    allreduce_accumulator(acc, group)
+    res = gptq_quantize_row_split(weights, acc, qargs, group=group, block_size=block_size, dampening_frac=dampening_frac)
+    out = []
+    for r in res:
+        parts = {k: getattr(r, k) for k in ("weight_packed", "weight_q", "weight_scale", "weight_zero_point",
+                                            "weight_g_idx") if getattr(r, k) is not None}
+        parts["weight_shape"] = r.weight_shape
         out.append(parts)
     return out

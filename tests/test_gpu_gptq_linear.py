@@ -76,7 +76,7 @@ def test_linear_vs_independent_oracle_mismatch_rate(dev, oracle):
     print(f"nibble mismatch rate vs independent LAPACK oracle: {rate:.3e}")
     # error feedback amplifies last-bit differences in U into flipped roundings; upstream itself
     # is not reproducible across BLAS thread counts at this level
-    assert rate < 2e-2
+    assert rate <= 1e-4      # 0 observed (65 536 nibbles); a regression of the factor or the sweep shows far above this
     np.testing.assert_array_equal(res[0].scale_f32.cpu().numpy(), o["scale"])
 
 

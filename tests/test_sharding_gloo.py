@@ -87,6 +87,80 @@ def test_gather_state_dict_world2_gloo():
     assert q.get(timeout=10) is True
 
 
+def test_plan_groups_splits_what_exceeds_a_fair_share():
+    from quantool_amd.engine.sharding import group_cost, plan_groups
+
+    # a Llama-3-8B layer on 8 ranks: down_proj (K = 14336) is two thirds of the work -> split (B);
+    # the K = 4096 groups are whole units (A) on distinct ranks
+    N = 196608
+    costs = [group_cost(14336, N, 4096), group_cost(4096, N, 6144), group_cost(4096, N, 4096), group_cost(4096, N, 28672)]
+    plan = plan_groups(costs, 8)
+    assert plan[0] == ("B", -1)
+    owners = [o for kind, o in plan[1:] if kind == "A"]
+    assert len(set(owners)) == len(owners)                    # no rank gets two whole groups while others idle
+    assert plan_groups(costs, 1) == [("A", 0)] * 4
+    # every rank computes the same plan
+    assert plan_groups(costs, 8) == plan
+    # Llama-3-70B's K = 28672 group is split at any world size > 1
+    big = [group_cost(28672, N, 8192), group_cost(8192, N, 10240), group_cost(8192, N, 8192), group_cost(8192, N, 57344)]
+    assert plan_groups(big, 2)[0] == ("B", -1) and plan_groups(big, 8)[0] == ("B", -1)
+
+
+def _row_split_worker(rank, world, port, q):
+    """Control flow of partitioning B's gather step on CPU tensors: the per-rank sweep is replaced by a
+    stand-in (the real one needs a GPU); what is checked is who sweeps which rows and how the rows of
+    every tensor come back together, including a rank that owns no row of a weight."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+
+        import quantool_amd.engine.gptq_linear as gl
+        from quantool_amd.engine.sharding import gptq_quantize_row_split
+
+        seen_rows = []
+
+        def fake_shared(weights, acc, qargs, **kw):
+            out = []
+            for w in weights:
+                seen_rows.append(int(w.shape[0]))
+                out.append(types.SimpleNamespace(
+                    weight_packed=(w[:, :4] * 1000).to(torch.int32), weight_q=None,
+                    weight_scale=w[:, :2].to(torch.bfloat16), weight_zero_point=None, weight_g_idx=None,
+                    dequantized=lambda dtype, w=w: (w * 2).to(dtype)))
+            return out
+
+        gl.gptq_quantize_shared = fake_shared
+        g = torch.Generator().manual_seed(5)
+        Ws = [torch.randn(r, 8, generator=g) for r in (7, 1, 4)]          # 1 row: rank 1 owns nothing of it
+        qa = types.SimpleNamespace(actorder="static")
+        res = gptq_quantize_row_split(Ws, None, qa, with_dequantized=True)
+        ok = seen_rows == ([4, 1, 2] if rank == 0 else [3, 2])
+        for w, r in zip(Ws, res):
+            ok &= torch.equal(r.weight_packed, (w[:, :4] * 1000).to(torch.int32))
+            ok &= torch.equal(r.weight_scale, w[:, :2].to(torch.bfloat16))
+            ok &= r.weight_zero_point is None and torch.equal(r.dequantized(torch.float32), w * 2)
+            ok &= r.weight_shape.tolist() == [w.shape[0], 8]
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_split_gather_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_row_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=10) for _ in range(2))
+    assert got == {0: True, 1: True}
+
+
 def test_row_slices_cover_every_row_once():
     for rows, world in [(10, 4), (2, 4), (4096, 8), (1, 2), (37, 2)]:
         sl = row_slices(rows, world)
