@@ -202,8 +202,11 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
 
             mine = {f"{n}::{k}": v for n, r in results.items() if plan_owner_is(plan, cal, n, rank)
                     for k, v in result_tensors(r).items()}
-            backend_dev = device if torch.distributed.get_backend() != "gloo" else None
-            merged = gather_state_dict(mine, dst=0, device=backend_dev)
+            if torch.distributed.get_backend() == "gloo":     # host-side backend (CPU rehearsals): ship host tensors
+                mine = {k: v.cpu() for k, v in mine.items()}
+                merged = gather_state_dict(mine, dst=0, device=None)
+            else:
+                merged = gather_state_dict(mine, dst=0, device=device)
             if rank == 0:
                 by_lin: Dict[str, dict] = {}
                 for key, t in merged.items():
