@@ -40,14 +40,19 @@ def my_units(costs: Sequence[float], world: int, rank: int) -> List[int]:
 
 
 def _flatten(state: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, list]:
+    """One byte buffer holding every tensor at a 16-byte aligned offset (a view of the buffer as the
+    tensor's dtype needs its offset divisible by the element size)."""
     meta, chunks, off = [], [], 0
+    dev = next(iter(state.values())).device if state else torch.device("cpu")
     for name in sorted(state):
         t = state[name].contiguous()
         nbytes = t.numel() * t.element_size()
         meta.append((name, str(t.dtype).replace("torch.", ""), tuple(t.shape), off, nbytes))
         chunks.append(t.reshape(-1).view(torch.uint8))
-        off += nbytes
-    dev = chunks[0].device if chunks else torch.device("cpu")
+        pad = (-nbytes) % 16
+        if pad:
+            chunks.append(torch.zeros(pad, dtype=torch.uint8, device=t.device))
+        off += nbytes + pad
     flat = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8, device=dev)
     return flat, meta
 

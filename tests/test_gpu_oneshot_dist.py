@@ -41,4 +41,4 @@ def test_oneshot_two_ranks(dev, tmp_path, mode):
             raise
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r} exited {p.returncode}:\n{out[-4000:]}"
+        assert p.returncode == 0, f"rank {r} exited {p.returncode}:\n" + "\n".join(o[-3000:] for o in outs)
