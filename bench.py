@@ -149,6 +149,20 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
     return outs
 
 
+def awq_layer(shape, weights, acts, qargs):
+    """One step of the AWQ mode (BASELINE.json configs[2]): the 20-point per-channel scale search,
+    apply, observer + round-to-nearest + int4 pack for the four mappings of one decoder layer."""
+    from quantool_amd.engine.awq_linear import awq_quantize_group
+
+    outs = {}
+    for gname, K, lins in shape.groups:
+        res = awq_quantize_group([weights[n] for n, _ in lins], [acts[gname]], qargs)
+        for (lname, _), r in zip(lins, res):
+            outs[f"{lname}.weight_packed"] = r.weight_packed
+            outs[f"{lname}.weight_scale"] = r.weight_scale
+    return outs
+
+
 def join_streams(dev):
     main = torch.cuda.current_stream(dev)
     for key, st in list(_STREAMS.items()):
@@ -224,6 +238,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
     ap.add_argument("--lanes", type=int, default=2, help="layers in flight (independent stream sets)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
+    ap.add_argument("--method", choices=["gptq", "awq"], default="gptq",
+                    help="gptq: the headline metric (BASELINE.json configs[1]); awq: configs[2], a second, separately "
+                         "labelled line (20-point scale search + RTN + pack per decoder layer)")
     ap.add_argument("--accumulate", choices=["single", "per-sample"], default="single",
                     help="single: one resident [N, K] activation batch per Linear group (BASELINE.md 2.2); per-sample: "
                          "512 calls of 384 tokens per group, the plugin path's calling pattern (staged on the device)")
@@ -276,9 +293,16 @@ def main():
         torch.cuda.synchronize()
 
     per_sample = args.accumulate == "per-sample"
+    awq = args.method == "awq"
+
+    def step(i):
+        if awq:
+            return awq_layer(shape, weights, acts, qargs)
+        return quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap,
+                              lane=i % max(1, args.lanes), per_sample=per_sample)
+
     for _ in range(args.warmup):
-        quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap, lane=_ % max(1, args.lanes),
-                       per_sample=per_sample)
+        step(_)
     join_streams(dev)
     barrier()
 
@@ -287,8 +311,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        kept.append(quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap,
-                                   lane=_ % max(1, args.lanes), per_sample=per_sample))
+        kept.append(step(_))
     t_enqueued = time.perf_counter() - t0      # host side done issuing; the device is still working
     join_streams(dev)
     if dist is not None:
@@ -338,6 +361,9 @@ def main():
     # (symmetric minimum) / device time of the kernel from HIP events on its stream
     alg_flops = sum(n_tokens * K * (K + 1) for _, K, _ in shape.groups) * args.steps
     alg_bytes = sum(n_tokens * K * 2 + K * K * 4 for _, K, _ in shape.groups) * args.steps
+    if awq:   # + one D^T D Gram pass per grid point and balance Linear (rows play the tokens' part)
+        alg_flops += sum(20 * R * K * (K + 1) for _, K, lins in shape.groups for _, R in lins) * args.steps
+        alg_bytes += sum(20 * (R * K * 2 + K * K * 4) for _, K, lins in shape.groups for _, R in lins) * args.steps
     achieved_tflops = alg_flops / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
     roofline = {
         "kernel": "xtx_kernel", "bound": "mfma", "achieved": round(achieved_tflops, 2),
@@ -355,20 +381,24 @@ def main():
     }
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not awq:
         cpu = cpu_baseline_port()
 
     if rank == 0:
         line = {
-            "metric": "quantized weights/sec (GPTQ int4, Llama-3-8B, 512 calib samples)",
+            "metric": ("quantized weights/sec (GPTQ int4, Llama-3-8B, 512 calib samples)" if not awq else
+                       "quantized weights/sec (AWQ int4, Llama-3-8B, 512 calib samples) [BASELINE.json configs[2], not the headline]"),
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {
-                "workload": (f"Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, "
-                             "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
-                             "1 decoder layer (7 Linears, 218103808 weights) per step per GPU"),
+                "workload": ((f"Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, "
+                              "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
+                              "1 decoder layer (7 Linears, 218103808 weights) per step per GPU") if not awq else
+                             ("Llama-3-8B-shaped random-init AWQ int4 g128 (W4A16, 20-point per-channel scale search, "
+                              "duo scaling), 512 synthetic calib samples x 384 tokens, 1 decoder layer (4 mappings, "
+                              "7 Linears, 218103808 weights) per step per GPU")),
                 "n_calibration_samples": args.samples, "seq_len": SEQ_LEN, "accumulate": args.accumulate,
                 "layers_per_step_per_gpu": 1, "sharding": f"layers over {world} rank(s), RCCL gather of packed state",
             },

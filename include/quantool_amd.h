@@ -147,13 +147,19 @@ int qt_awq_scales(const float* x_abs_sum, int64_t n_tokens, const float* w_sum, 
                   int n_grid, int duo_scaling, float* scales, qt_stream_t stream);
 /* Mirror the lower triangle of the Gram sum into the upper one (G full symmetric afterwards). */
 int qt_symmetrize_lower(float* G, int K, qt_stream_t stream);
-/* loss_out[0] (device fp32) = mean((X W^T - X Wq^T)^2) with Wq = pseudo_quant(W*s)/s, evaluated as
- * <G, D^T D>_F / (n_tokens * R), D = W - Wq rounded to bf16, G = X^T X (lower triangle read; see the
- * awq.hip header). */
+/* Search loss of one grid point for one balance Linear:  L = mean((X W^T - X Wq^T)^2) with
+ * Wq = pseudo_quant(W*s)/s, evaluated as <G, D^T D>_F / (n_tokens * R), D = W - Wq, G = X^T X (full
+ * symmetric, see qt_symmetrize_lower).  exact == 0: D rounded to bf16, D^T D on the bf16 MFMA (moves L
+ * by < 5e-4 relative; the form the 20-point search runs).  exact != 0: D and D^T D in fp32 on the f32
+ * MFMA (16x the MFMA time; used to re-score grid points whose fast losses are closer than that error).
+ * loss_out[0] = (accumulate ? loss_out[0] : 0) + weight * L   -- a mapping's loss is the row-weighted
+ * mean over its balance Linears, so the caller passes weight = R / total rows. */
 size_t qt_awq_loss_workspace_bytes(int R, int K);
 int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
-                int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, float* loss_out,
-                void* workspace, size_t workspace_bytes, qt_stream_t stream);
+                int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, int exact, float weight,
+                int accumulate, float* loss_out, void* workspace, size_t workspace_bytes, qt_stream_t stream);
+/* index_out[0] = index of the first minimum of values[0..n) (n <= 1024): the grid search's argmin. */
+int qt_argmin_f32(const float* values, int n, int32_t* index_out, qt_stream_t stream);
 /* out[R,K] (W's dtype, leading dimension ldo) = pseudo_quant(W * s) / s: the trial weights of one
  * grid point, for mappings whose search loss is measured on a parent module's output (q/k/v under
  * self_attn, gate/up under mlp) rather than on the balance Linear's own.  out may alias W. */

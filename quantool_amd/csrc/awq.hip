@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void awq_scales_kernel(const float* __restric
 // with leading dimension K (the layout qt_xtx_accumulate reads: rows play the role of tokens).
 // !DIFF: out[r][k] = pseudo_quant(w * s_k) / s_k in the weight's own dtype, leading dimension ldo
 // (the trial weights of one grid point when the search loss needs a forward of the parent module).
-template <bool DIFF>
+template <int DIFF>   // 0: trial weights in the weight dtype; 1: D as bf16; 2: D as fp32 (exact re-scoring)
 __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __restrict__ W, int dtype, int R, int K,
                                                               int64_t ldw, const float* __restrict__ s, int gs,
                                                               int symmetric, int num_bits, void* __restrict__ out,
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
                 const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
                 q = (fminf(fmaxf(rintf(v / sc) + z, 0.0f), max_int) - z) * sc;
             }
-            if (DIFF) ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(wv - q / s[k]);
+            if (DIFF == 1) ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(wv - q / s[k]);
+            else if (DIFF == 2) ((float*)out)[(size_t)r * K + k] = wv - q / s[k];
             else qt_store_w(out, dtype, (size_t)r * ldo + k, q / s[k]);
         }
         return;
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
                 const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
                 q = (fminf(fmaxf(rintf(ws[e] / sc) + z, 0.0f), max_int) - z) * sc;
             }
-            if (DIFF) ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(w[e] - q / s[k]);
+            if (DIFF == 1) ((__bf16*)out)[(size_t)r * K + k] = (__bf16)(w[e] - q / s[k]);
+            else if (DIFF == 2) ((float*)out)[(size_t)r * K + k] = w[e] - q / s[k];
             else qt_store_w(out, dtype, (size_t)r * ldo + k, q / s[k]);
         }
     }
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ G, 
 }
 
 __global__ __launch_bounds__(256) void partial_sum_f64_kernel(const float* __restrict__ partial, int n, double scale,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int accumulate) {
     __shared__ double red[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
@@ -255,7 +257,30 @@ __global__ __launch_bounds__(256) void partial_sum_f64_kernel(const float* __res
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0f) + (float)(red[0] * scale);
+}
+
+// index of the first minimum of n <= 1024 values (the grid search's argmin: upstream keeps the first
+// ratio whose loss is strictly smaller, i.e. the first index among ties); NaN never wins
+__global__ __launch_bounds__(64) void argmin_first_kernel(const float* __restrict__ v, int n, int32_t* __restrict__ out) {
+    float best = INFINITY;
+    int bi = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float x = v[i];
+        if (x < best) {
+            best = x;
+            bi = i;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_down(best, off);
+        const int oi = __shfl_down(bi, off);
+        if (ob < best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if (threadIdx.x == 0) out[0] = bi;
 }
 
 // out[r][k] = W[r][k] * s[k]  (fp32 product rounded to the output dtype, as `weight * scales`)
@@ -395,17 +420,20 @@ extern "C" int qt_symmetrize_lower(float* G, int K, qt_stream_t stream_) {
 
 extern "C" size_t qt_awq_loss_workspace_bytes(int R, int K) {
     if (R <= 0 || K <= 0) return 0;
-    // Db [R,K] bf16 + C [K,K] fp32 + per-row partials + the Gram kernel's own workspace
-    return qt_align_up((size_t)R * K * 2, 256) + (size_t)K * K * 4 + qt_align_up((size_t)K * 4, 256) +
+    // D [R,K] (bf16 for the fast form, fp32 for the exact one: sized for fp32) + C [K,K] fp32 + per-row
+    // partials + the Gram kernel's own workspace
+    return qt_align_up((size_t)R * K * 4, 256) + (size_t)K * K * 4 + qt_align_up((size_t)K * 4, 256) +
            qt_xtx_workspace_bytes(R, K) + 1024;
 }
 
 extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int group_size,
-                           int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, float* loss_out,
-                           void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+                           int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, int exact,
+                           float weight, int accumulate, float* loss_out, void* workspace, size_t workspace_bytes,
+                           qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(W && s && Gfull && loss_out && R > 0 && K > 0 && n_tokens > 0, "qt_awq_loss: bad arguments");
     QT_CHECK_ARG(K % 8 == 0, "qt_awq_loss: K=%d must be a multiple of 8", K);
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_awq_loss: dtype %d unsupported", w_dtype);
     const int gs = group_size <= 0 ? K : group_size;
     if (K % gs != 0) {
         qt_set_error("qt_awq_loss: group_size %d unsupported", gs);
@@ -418,21 +446,45 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
         return QT_ERR_WORKSPACE;
     }
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
-    __bf16* Db = (__bf16*)ws;
-    float* C = (float*)(ws + qt_align_up((size_t)R * K * 2, 256));
+    void* D = (void*)ws;
+    float* C = (float*)(ws + qt_align_up((size_t)R * K * 4, 256));
     float* partial = C + (size_t)K * K;
     char* xws = (char*)partial + qt_align_up((size_t)K * 4, 256);
     const size_t xws_bytes = workspace_bytes - (size_t)(xws - (char*)workspace);
-    hipLaunchKernelGGL(awq_pseudo_quant_kernel<true>, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s,
-                       gs, symmetric, num_bits, (void*)Db, (int64_t)K);
-    QT_LAUNCH_CHECK();
-    QT_HIP(hipMemsetAsync(C, 0, (size_t)K * K * 4, stream));
-    const int rc = qt_xtx_accumulate(Db, QT_BF16, R, K, K, C, xws, xws_bytes, stream_);
-    if (rc) return rc;
+    if (!exact) {
+        hipLaunchKernelGGL(awq_pseudo_quant_kernel<1>, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s,
+                           gs, symmetric, num_bits, D, (int64_t)K);
+        QT_LAUNCH_CHECK();
+        QT_HIP(hipMemsetAsync(C, 0, (size_t)K * K * 4, stream));
+        const int rc = qt_xtx_accumulate(D, QT_BF16, R, K, K, C, xws, xws_bytes, stream_);
+        if (rc) return rc;
+    } else {
+        // D in fp32 and D^T D on the f32 MFMA: one ascending-k fmaf chain per entry, no bf16 rounding of
+        // D.  16x the MFMA time of the fast form: used only to break near-ties of the 20-point search.
+        hipLaunchKernelGGL(awq_pseudo_quant_kernel<2>, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s,
+                           gs, symmetric, num_bits, D, (int64_t)K);
+        QT_LAUNCH_CHECK();
+        SgemmArgs g;
+        g.A = (const float*)D; g.lda = K;
+        g.B = (const float*)D; g.ldb = K;
+        g.Cin = nullptr; g.ldcin = 0;
+        g.Cout = C; g.ldcout = K;
+        g.M = K; g.N = K; g.kdim = R; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SET;
+        const int rc = qt_sgemm_tn(g, stream);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(sym_dot_rows_kernel, dim3(K), dim3(256), 0, stream, Gfull, (const float*)C, K, partial);
     QT_LAUNCH_CHECK();
     hipLaunchKernelGGL(partial_sum_f64_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, K,
-                       1.0 / ((double)n_tokens * (double)R), loss_out);
+                       (double)weight / ((double)n_tokens * (double)R), loss_out, accumulate);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+extern "C" int qt_argmin_f32(const float* values, int n, int32_t* index_out, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(values && index_out && n > 0 && n <= 1024, "qt_argmin_f32: bad arguments (n <= 1024)");
+    hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, stream, values, n, index_out);
     QT_LAUNCH_CHECK();
     return QT_OK;
 }
@@ -452,7 +504,7 @@ extern "C" int qt_awq_pseudo_quantize(const void* W, int w_dtype, int R, int K, 
     const size_t esz = qt_dtype_size(w_dtype);
     for (int row0 = 0; row0 < R; row0 += 32768) {   // gridDim.y limit
         const int rows = (R - row0 < 32768) ? R - row0 : 32768;
-        hipLaunchKernelGGL(awq_pseudo_quant_kernel<false>, dim3(K / gs, rows), dim3(64), 0, stream,
+        hipLaunchKernelGGL(awq_pseudo_quant_kernel<0>, dim3(K / gs, rows), dim3(64), 0, stream,
                            (const void*)((const char*)W + (size_t)row0 * ldw * esz), w_dtype, rows, K, ldw, s, gs,
                            symmetric, num_bits, (void*)((char*)out + (size_t)row0 * ldo * esz), ldo);
         QT_LAUNCH_CHECK();

@@ -61,15 +61,47 @@ def awq_search(weights: Sequence[torch.Tensor], batches: Iterable[torch.Tensor],
         ops.awq_weight_mean_accumulate(w, gs, w_sum)
         n_rows += w.shape[0]
     scales = ops.awq_scales(x_sum, n_tokens, w_sum, n_rows, n_grid, duo_scaling)
-    # the loss of a mapping is the mean over ALL balance layers' outputs = row-weighted mean
-    losses = torch.zeros(n_grid, dtype=torch.float32, device=dev)
-    tmp = torch.zeros(1, dtype=torch.float32, device=dev)
-    for gi in range(n_grid):
-        for w in weights:
-            ops.awq_loss(w, scales[gi], gs, qargs.symmetric, qargs.num_bits, G, n_tokens, tmp)
-            losses[gi] += tmp[0] * (w.shape[0] / n_rows)
-    best = torch.argmin(losses)
+    losses, best = search_losses(weights, scales, G, n_tokens, qargs)
     return scales, losses, best, n_tokens
+
+
+#: The fast search loss rounds D = W - Wq to bf16 (moves a loss by < 5e-4 relative).  Grid
+#: points whose fast losses are within this relative distance of the best one are re-scored exactly.
+NEAR_TIE_RTOL = 1.5e-3
+
+
+def search_losses(weights: Sequence[torch.Tensor], scales: torch.Tensor, G: torch.Tensor, n_tokens: int,
+                  qargs: QuantArgs, near_tie_rtol: Optional[float] = None):
+    """Losses of every grid point and the arg-min, all on the device: the row-weighted mean over the
+    mapping's balance Linears is accumulated by ``qt_awq_loss`` itself, the arg-min is ``qt_argmin_f32``.
+    The host looks at the 20 numbers once, to decide whether any runner-up is closer to the winner than
+    the bf16 rounding of D can resolve; those candidates (rare) are evaluated again with D and D^T D in
+    fp32 and the arg-min is retaken among them -- so the chosen scales do not hinge on that rounding."""
+    n_grid = scales.shape[0]
+    gs = qargs.kernel_group_size
+    dev = G.device
+    n_rows = sum(int(w.shape[0]) for w in weights)
+    losses = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+
+    def score(gi: int, exact: bool):
+        for j, w in enumerate(weights):
+            ops.awq_loss(w, scales[gi], gs, qargs.symmetric, qargs.num_bits, G, n_tokens, losses[gi:gi + 1],
+                         exact=exact, weight=w.shape[0] / n_rows, accumulate=j > 0)
+
+    for gi in range(n_grid):
+        score(gi, False)
+    best = ops.argmin_first(losses)
+    rtol = NEAR_TIE_RTOL if near_tie_rtol is None else near_tie_rtol
+    host = losses.tolist()                                   # one small sync per mapping
+    b = int(best.item())
+    close = [i for i, l in enumerate(host) if l <= host[b] * (1.0 + rtol) or l != l]
+    if len(close) > 1:
+        exact_losses = torch.full((n_grid,), float("inf"), dtype=torch.float32, device=dev)
+        for gi in close:
+            score(gi, True)
+            exact_losses[gi] = losses[gi]
+        best = ops.argmin_first(exact_losses)
+    return losses, best.to(torch.int64).reshape(())
 
 
 def rtn_finalize(ws: torch.Tensor, qargs: QuantArgs, s: Optional[torch.Tensor] = None,

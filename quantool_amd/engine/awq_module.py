@@ -126,7 +126,7 @@ def _first(out):
     return out[0] if isinstance(out, (tuple, list)) else out
 
 
-def _as_bf16_rows(x: torch.Tensor) -> torch.Tensor:
+def _as_rows16(x: torch.Tensor) -> torch.Tensor:
     x = x.reshape(-1, x.shape[-1])
     return ops.as_act16(x)
 
@@ -142,7 +142,7 @@ class _Capture:
         self.parent_calls: List[tuple] = []      # (args, kwargs) per batch, multi-balance mappings only
 
     def on_balance_input(self, _mod, args):
-        x = _as_bf16_rows(args[0])
+        x = _as_rows16(args[0])
         ops.act_stats_accumulate(x, abs_sum=self.x_abs_sum)
         if self.gram is not None:
             ops.xtx_accumulate(x, self.gram)
@@ -165,10 +165,11 @@ def _search(mp: ResolvedMapping, cap: _Capture, qargs: QuantArgs, n_grid: int, d
     scales = ops.awq_scales(cap.x_abs_sum, cap.n_tokens, w_sum, n_rows, n_grid, duo_scaling)
     losses = torch.zeros(n_grid, dtype=torch.float32, device=dev)
     if mp.single:
+        from .awq_linear import search_losses
+
         ops.symmetrize_lower(cap.gram)
-        w = mp.balance[0].weight.data
-        for gi in range(n_grid):
-            ops.awq_loss(w, scales[gi], gs, qargs.symmetric, qargs.num_bits, cap.gram, cap.n_tokens, losses[gi:gi + 1])
+        losses, best = search_losses([mp.balance[0].weight.data], scales, cap.gram, cap.n_tokens, qargs)
+        return scales, losses, best
     else:
         originals = [lin.weight.data.clone() for lin in mp.balance]
         fp_out = [_first(mp.parent(*a, **kw)).float() for a, kw in cap.parent_calls]
@@ -184,7 +185,9 @@ def _search(mp: ResolvedMapping, cap: _Capture, qargs: QuantArgs, n_grid: int, d
         finally:
             for lin, w0 in zip(mp.balance, originals):
                 lin.weight.data.copy_(w0)
-    return scales, losses, torch.argmin(losses)
+    # multi-consumer mapping: the parent module's own forward (the caller's torch code) produced the
+    # losses above; the arg-min of the 20 numbers is the device kernel the Gram form uses
+    return scales, losses, ops.argmin_first(losses).to(torch.int64).reshape(())
 
 
 def _apply(mp: ResolvedMapping, s: torch.Tensor) -> None:

@@ -328,8 +328,9 @@ def symmetrize_lower(G: torch.Tensor) -> None:
 
 
 def awq_loss(W: torch.Tensor, s: torch.Tensor, group_size: int, symmetric: bool, num_bits: int, Gfull: torch.Tensor,
-             n_tokens: int, out: torch.Tensor) -> None:
-    """out[0] (device fp32) = search loss for the per-channel scales s[K]."""
+             n_tokens: int, out: torch.Tensor, *, exact: bool = False, weight: float = 1.0,
+             accumulate: bool = False) -> None:
+    """out[0] (device fp32) = (accumulate ? out[0] : 0) + weight * search loss for the scales s[K]."""
     lib = load()
     R, K = _w2d(W)
     _req(s, torch.float32, "s", 1)
@@ -339,7 +340,18 @@ def awq_loss(W: torch.Tensor, s: torch.Tensor, group_size: int, symmetric: bool,
     ws = workspace(lib.qt_awq_loss_workspace_bytes(R, K), W.device, "awq_loss")
     check("qt_awq_loss", lib.qt_awq_loss(W.data_ptr(), _dtype_code(W), R, K, W.stride(0), s.data_ptr(), group_size,
                                          int(bool(symmetric)), num_bits, Gfull.data_ptr(), int(n_tokens),
-                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+                                         int(bool(exact)), float(weight), int(bool(accumulate)), out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream()))
+
+
+def argmin_first(values: torch.Tensor) -> torch.Tensor:
+    """Device int32[1]: index of the first minimum (ties keep the lowest index, as upstream's search loop)."""
+    lib = load()
+    _req(values, torch.float32, "values", 1)
+    assert values.is_contiguous()
+    out = torch.empty(1, dtype=torch.int32, device=values.device)
+    check("qt_argmin_f32", lib.qt_argmin_f32(values.data_ptr(), values.numel(), out.data_ptr(), _stream()))
+    return out
 
 
 def awq_pseudo_quantize(W: torch.Tensor, s: torch.Tensor, group_size: int, symmetric: bool, num_bits: int,

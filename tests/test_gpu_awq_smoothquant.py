@@ -137,3 +137,84 @@ def test_rtn_matches_sweep_with_identity_factor(dev, oracle):
     Qt2, _ = ops.gptq_sweep(W.clone(), U, st, zt, g_idx, 128, 4)
     torch.cuda.synchronize()
     assert torch.equal(Qt, Qt2)
+
+
+# ---------------------------------------------------------------------------- near-ties / config 3
+def test_awq_exact_rescoring_matches_the_fp64_loss_and_breaks_ties_by_first_index(dev, oracle):
+    """The fast search loss rounds D to bf16 (3e-3 test tolerance above).  Candidates closer to the winner
+    than that are re-scored with D and D^T D in fp32: forced here for EVERY grid point, the re-scored
+    losses must sit on the oracle's fp64 direct losses (1e-5 relative), and the arg-min must be the
+    oracle's.  An exact tie (constant x_mean and w_mean make all 20 scale vectors equal) keeps index 0,
+    as upstream's strictly-smaller search loop does."""
+    from quantool_amd.engine import awq_linear
+    from quantool_amd.engine.awq_linear import awq_search
+    from quantool_amd.engine.schemes import QuantArgs
+
+    rng = np.random.default_rng(21)
+    K = 256
+    xb = synth_activations(700, K, seed=21)
+    Wn = [synth_weight(48, K, seed=31), synth_weight(24, K, seed=32)]
+    Wb = [oracle.f32_to_bf16_bits(w) for w in Wn]
+    r = oracle.awq_best_scale(xb, [oracle.bf16_bits_to_f32(b) for b in Wb], group_size=128)
+    qa = QuantArgs()
+    old = awq_linear.NEAR_TIE_RTOL
+    awq_linear.NEAR_TIE_RTOL = 1e9               # everything is "close": every grid point is re-scored exactly
+    try:
+        scales, losses, best, _ = awq_search([bits_to_bf16_tensor(b, dev) for b in Wb], [bits_to_bf16_tensor(xb, dev)], qa)
+    finally:
+        awq_linear.NEAR_TIE_RTOL = old
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses.cpu().numpy(), r["losses"], rtol=1e-5)
+    assert int(best.item()) == r["best_ratio_idx"]
+    # exact tie: |x| constant per channel over tokens AND group-normalised |w| constant -> s identical for all ratios
+    X = torch.ones((64, K), device=dev, dtype=torch.bfloat16)
+    X[::2] *= -1
+    W = torch.full((16, K), 0.25, device=dev, dtype=torch.bfloat16)
+    W[:, ::2] *= -1
+    scales, losses, best, _ = awq_search([W], [X], qa)
+    l = losses.cpu().numpy()
+    assert np.all(l == l[0]) and int(best.item()) == 0
+    del rng
+
+
+def test_awq_full_size_config3_properties(dev):
+    """BASELINE config 3 at the real width (K = 4096, gate+up = 28 672 rows, 196 608 tokens) through
+    size-independent properties: the chosen ratio's loss is the minimum of the 20 and not above ratio 0's;
+    the scales are finite, positive and normalised (sqrt(max * min) = 1); the exact fp32 re-evaluation of the
+    winner agrees with the fast bf16-D form within its stated error; the packed words decode back to the
+    levels; and the smoothed weight divided by s returns W to bf16 rounding."""
+    from quantool_amd.engine.awq_linear import awq_quantize_group, awq_search
+    from quantool_amd.engine.schemes import QuantArgs
+    from quantool_amd.hip import ops
+
+    K, N = 4096, 512 * 384
+    g = torch.Generator(device=dev).manual_seed(3)
+    X = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+    gain = torch.ones(K, device=dev)
+    gain[torch.randperm(K, generator=g, device=dev)[: K // 100]] = 10.0
+    for t0 in range(0, N, 16384):
+        X[t0:t0 + 16384] = (torch.randn((16384, K), generator=g, device=dev) * gain).to(torch.bfloat16)
+    Ws = [(torch.randn((14336, K), generator=g, device=dev) * 0.02).to(torch.bfloat16) for _ in range(2)]
+    qa = QuantArgs()
+    scales, losses, best, n_tok = awq_search(Ws, [X], qa)
+    b = int(best.item())
+    l = losses.cpu().numpy()
+    assert n_tok == N and np.all(np.isfinite(l)) and l[b] == l.min() and l[b] <= l[0]
+    s = scales[b]
+    assert bool(torch.isfinite(s).all()) and float(s.min()) > 0
+    assert abs(float(torch.sqrt(s.max() * s.min())) - 1.0) < 1e-4
+    # exact re-evaluation of the winner vs the fast form
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    ops.symmetrize_lower(G)
+    ex = torch.zeros(1, device=dev)
+    for j, w in enumerate(Ws):
+        ops.awq_loss(w, s.contiguous(), 128, True, 4, G, N, ex, exact=True, weight=0.5, accumulate=j > 0)
+    assert abs(float(ex.item()) - l[b]) <= 1e-3 * l[b]
+    res = awq_quantize_group(Ws, [X], qa)
+    for w, r in zip(Ws, res):
+        words = r.weight_packed.cpu().numpy().view(np.uint32)
+        lv = ((words[:, :, None] >> (4 * np.arange(8, dtype=np.uint32))[None, None, :]) & 0xF).reshape(w.shape[0], -1).astype(np.int8) - 8
+        assert np.array_equal(lv, r.Qt.t().cpu().numpy())
+        back = ops.scale_columns(r.scaled_weight, r.smoothing_scales, divide=True)
+        assert float((back.float() - w.float()).abs().max()) <= 2 ** -7 * float(w.float().abs().max())
