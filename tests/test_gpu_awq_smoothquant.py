@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import bits_to_bf16_tensor, synth_weight
+from tests.util import bits_to_bf16_tensor, synth_activations, synth_weight
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
