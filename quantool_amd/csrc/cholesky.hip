@@ -6,18 +6,28 @@
 // Ut = J R^T J upper, so Hd^-1 = (Ut^-1)^T (Ut^-1) and, by uniqueness of the Cholesky factor,
 //     U = Ut^-1 = J R^-T J = flat-reverse(Y),   Y = R^-T (lower).
 // Cost 2/3 K^3 flops (vs 4/3 K^3) and every block recurrence below is a k-major "TN" product,
-// i.e. one fp32-MFMA kernel (sgemm_tn) serves the whole chain:
-//   potrf, block row j :  P = A[j, j:] - sum_{p<j} R[p, j]^T R[p, j:]        (sgemm SUB)
-//                         R_jj = chol(P_jj), Dinv_j = R_jj^-1                 (panel kernel)
-//                         R[j, j+1:] = Dinv_j^T P[:, nb:]                     (sgemm SET)
-//   R^-T,  block row i :  T = sum_{p<i} R[p, i]^T Y[p, :i]   (Y lower => skip k < n0)
-//                         Y[i, :i] = -Dinv_i^T T ;  Y[i, i] = Dinv_i^T
+// i.e. one fp32-MFMA kernel (sgemm_tn) serves the whole chain.  Two block sizes: NB = 128 for the
+// latency-bound panel kernels, NBO = 512 for everything that carries the K^3 work, so that work
+// runs as a few dozen large GEMMs (k = 512, hundreds to thousands of 128x128 tiles, no split-K
+// slabs) instead of one M = 128 split-K product per 128 columns:
+//   potrf, RIGHT-looking over 512-wide outer blocks J, left-looking inside one (all in place in A):
+//     block row j of J :  A[j, j:] -= sum_{p in J, p<j} R[p, j]^T R[p, j:]   (sgemm SUB, k <= 384)
+//                         R_jj = chol(A_jj), 32x32 inverses                   (potf2_kernel)
+//                         R[j, j+1:] = R_jj^-T A[j, j+1:]                     (trsm_rt_kernel)
+//     after block J    :  A[J1:, J1:] -= R[J, J1:]^T R[J, J1:]                (sgemm SUB, k = 512,
+//                                                                              upper-triangle tiles only)
+//   R^-T by 512-row block rows I (Y lower, so the k range of a tile starts at its first column):
+//     inside I         :  Y_II by the 128-row recurrence  T = sum_{p in I, p<i} R[p, i]^T Y[p, I0:i];
+//                         Y[i, I0:i] = -Dinv_i^T T ;  Y[i, i] = Dinv_i^T     (k <= 384)
+//     left of I        :  T_I = sum_{p<I0} R[p, I]^T Y[p, :I0]               (sgemm SET, k = I0)
+//                         Y[I, :I0] = -Y_II T_I = -(Y_II^T)^T T_I             (transpose + sgemm NEG, k = 512)
 #include "common.h"
 #include "sgemm_tn.h"
 
 namespace {
 
 constexpr int NB = 128;
+constexpr int NBO = 512;     // outer block of the K^3 work
 constexpr int LDP = NB + 1;  // padded LDS leading dimension
 
 // ---- panel kernels --------------------------------------------------------------------------
@@ -61,8 +71,9 @@ __device__ __forceinline__ void mma32_tn(const float* A, int lda, const float* B
     }
 }
 
-__global__ __launch_bounds__(256) void potf2_kernel(const float* __restrict__ P, int64_t ldp, int n,
-                                                    float* __restrict__ Rout, int64_t ldr,
+// P and Rout may be the same block (the factorisation runs in place): no __restrict__ on them.
+__global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp, int n,
+                                                    float* Rout, int64_t ldr,
                                                     float* __restrict__ Rd, int32_t* info, int col0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* As = sm;                // [NB][LDA]
@@ -209,9 +220,10 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* __restrict__ P,
 // of the k indices: the k order of these sums is free), so Z never round-trips through LDS;
 // only the A operands (X_b, -R[b,a], k-major as stored) are read from LDS, one b32 per MFMA.
 //   Rd : dense 128x128 R followed by D32[4][32][32], D32[b][k][i] = X_b[k][i] (potf2_kernel)
+// B and Z may be the same panel (in place: a thread reads its columns before it writes them).
 __global__ __launch_bounds__(256) void trsm_rt_kernel(const float* __restrict__ Rd, int n,
-                                                      const float* __restrict__ B, int64_t ldb,
-                                                      float* __restrict__ Z, int64_t ldz, int ncols) {
+                                                      const float* B, int64_t ldb,
+                                                      float* Z, int64_t ldz, int ncols) {
     extern __shared__ __attribute__((aligned(16))) float Rs[];  // [RD_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < RD_STRIDE / 4; e += 256) ((f32x4*)Rs)[e] = ((const f32x4*)Rd)[e];
@@ -336,6 +348,24 @@ __global__ __launch_bounds__(128) void trinv_batched_kernel(const float* __restr
     }
 }
 
+// XT[k][m] = Y_II[m][k] for a w x w diagonal block of the lower-triangular Y (entries above the diagonal
+// of Y are not initialised outside the 128-blocks on the diagonal: written as zeros here)
+__global__ __launch_bounds__(256) void transpose_lower_block_kernel(const float* __restrict__ Y, int64_t ldy, int w,
+                                                                    float* __restrict__ XT, int ldx) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // XT rows k = by.., cols m = bx..
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int m = bx + r, k = by + tx;                   // read Y_II[m][k], coalesced along k
+        tile[r][tx] = (m < w && k < w && k <= m) ? Y[(size_t)m * ldy + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = by + r, m = bx + tx;
+        if (k < w && m < w) XT[(size_t)k * ldx + m] = tile[tx][r];
+    }
+}
+
 // In-place flat reversal of the lower-triangular Y into the upper-triangular U:
 // U[i][j] = Y[K-1-i][K-1-j] for j >= i, strict lower triangle of U = 0.
 __global__ __launch_bounds__(256) void flat_reverse_lower_to_upper_kernel(float* __restrict__ U, int K) {
@@ -371,8 +401,10 @@ __global__ __launch_bounds__(256) void identity_if_failed_kernel(float* __restri
 extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
     if (K <= 0) return 0;
     const size_t nb = (K + NB - 1) / NB;
-    // P panel [128, K] + T panel [128, K] + Rd, Dinv [nb][128*128] each + split-K slabs
-    return 2 * (size_t)NB * K * 4 + nb * (NB * NB + RD_STRIDE) * 4 + (size_t)32 * NB * K * 4 + 256;
+    // T panel [128, K] + T_I panel [512, K] + X_II [512, 512] + Rd, Dinv [nb][128*128] each + split-K slabs
+    // (a split product writes splits * M * N floats with splits <= 2048 workgroups / tiles: <= 2048 * 128 * 128)
+    const size_t split = (size_t)2048 * NB * NB * 4 + (size_t)NBO * K * 4;
+    return (size_t)NB * K * 4 + (size_t)NBO * K * 4 + (size_t)NBO * NBO * 4 + nb * (NB * NB + RD_STRIDE) * 4 + split + 256;
 }
 
 extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
@@ -386,12 +418,13 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     }
     const int nblk = (K + NB - 1) / NB;
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
-    float* P = (float*)ws;
-    float* T = P + (size_t)NB * K;
-    float* Rd = T + (size_t)NB * K;
+    float* T = (float*)ws;
+    float* TI = T + (size_t)NB * K;
+    float* XT = TI + (size_t)NBO * K;
+    float* Rd = XT + (size_t)NBO * NBO;
     float* Dinv = Rd + (size_t)nblk * RD_STRIDE;
     float* split_ws = Dinv + (size_t)nblk * NB * NB;
-    const size_t split_ws_bytes = (size_t)32 * NB * K * 4;
+    const size_t split_ws_bytes = (size_t)2048 * NB * NB * 4 + (size_t)NBO * K * 4;
     float* Y = U;
     const size_t inv_lds = (size_t)(NB * LDT + NB * LDP) * sizeof(float);
     const size_t potf2_lds = (size_t)(NB * LDA + 4 * 32 * 32) * sizeof(float);
@@ -409,51 +442,96 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     }));
     QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), stream));
 
-    // ---- A = R^T R, left-looking by block rows ----
-    for (int j = 0; j < nblk; ++j) {
-        const int j0 = j * NB, nbj = (K - j0 < NB) ? K - j0 : NB;
-        SgemmArgs g;
-        g.A = A + j0; g.lda = K;
-        g.B = A + j0; g.ldb = K;
-        g.Cin = A + (size_t)j0 * K + j0; g.ldcin = K;
-        g.Cout = P; g.ldcout = K;
-        g.M = nbj; g.N = K - j0; g.kdim = j0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
-        g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
-        int rc = qt_sgemm_tn(g, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), potf2_lds, stream, (const float*)P, (int64_t)K, nbj,
-                           A + (size_t)j0 * K + j0, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0);
-        QT_LAUNCH_CHECK();
-        const int rest = K - j0 - nbj;
-        if (rest > 0) {
-            hipLaunchKernelGGL(trsm_rt_kernel, dim3((rest + 127) / 128), dim3(256), RD_STRIDE * sizeof(float), stream,
-                               (const float*)(Rd + (size_t)j * RD_STRIDE), nbj, (const float*)(P + nbj), (int64_t)K,
-                               A + (size_t)j0 * K + j0 + nbj, (int64_t)K, rest);
+    // ---- A = R^T R: right-looking over 512-wide outer blocks, left-looking inside one; in place ----
+    for (int J0 = 0; J0 < K; J0 += NBO) {
+        const int J1 = (K - J0 < NBO) ? K : J0 + NBO;
+        for (int j0 = J0; j0 < J1; j0 += NB) {
+            const int j = j0 / NB, nbj = (K - j0 < NB) ? K - j0 : NB;
+            float* Ajj = A + (size_t)j0 * K + j0;
+            if (j0 > J0) {
+                // rows J0..j0 of this outer block are final: fold them into block row j
+                SgemmArgs g;
+                g.A = A + (size_t)J0 * K + j0; g.lda = K;
+                g.B = A + (size_t)J0 * K + j0; g.ldb = K;
+                g.Cin = Ajj; g.ldcin = K;
+                g.Cout = Ajj; g.ldcout = K;
+                g.M = nbj; g.N = K - j0; g.kdim = j0 - J0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+                int rc = qt_sgemm_tn(g, stream);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), potf2_lds, stream, (const float*)Ajj, (int64_t)K, nbj,
+                               Ajj, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0);
             QT_LAUNCH_CHECK();
+            const int rest = K - j0 - nbj;
+            if (rest > 0) {
+                hipLaunchKernelGGL(trsm_rt_kernel, dim3((rest + 127) / 128), dim3(256), RD_STRIDE * sizeof(float),
+                                   stream, (const float*)(Rd + (size_t)j * RD_STRIDE), nbj, (const float*)(Ajj + nbj),
+                                   (int64_t)K, Ajj + nbj, (int64_t)K, rest);
+                QT_LAUNCH_CHECK();
+            }
+        }
+        const int rem = K - J1;
+        if (rem > 0) {
+            // the K^3/3 of the factorisation: one SYRK-shaped update per outer block, upper tiles only
+            SgemmArgs g;
+            g.A = A + (size_t)J0 * K + J1; g.lda = K;
+            g.B = A + (size_t)J0 * K + J1; g.ldb = K;
+            g.Cin = A + (size_t)J1 * K + J1; g.ldcin = K;
+            g.Cout = A + (size_t)J1 * K + J1; g.ldcout = K;
+            g.M = rem; g.N = rem; g.kdim = J1 - J0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+            g.upper_only = 1;
+            int rc = qt_sgemm_tn(g, stream);
+            if (rc) return rc;
         }
     }
     // ---- all diagonal-block inverses at once ----
     hipLaunchKernelGGL(trinv_batched_kernel, dim3(nblk), dim3(NB), inv_lds, stream, (const float*)Rd, K, Dinv, Y,
                        (int64_t)K);
     QT_LAUNCH_CHECK();
-    // ---- Y = R^-T by block rows ----
-    for (int i = 1; i < nblk; ++i) {
-        const int i0 = i * NB, nbi = (K - i0 < NB) ? K - i0 : NB;
+    // ---- Y = R^-T by 512-row block rows ----
+    for (int I0 = 0; I0 < K; I0 += NBO) {
+        const int I1 = (K - I0 < NBO) ? K : I0 + NBO;
+        const int Wi = I1 - I0;
+        // the diagonal 512-block Y_II by the 128-row recurrence (short k)
+        for (int i0 = I0 + NB; i0 < I1; i0 += NB) {
+            const int i = i0 / NB, nbi = (K - i0 < NB) ? K - i0 : NB;
+            SgemmArgs g;
+            g.A = A + (size_t)I0 * K + i0; g.lda = K;
+            g.B = Y + (size_t)I0 * K + I0; g.ldb = K;
+            g.Cin = nullptr; g.ldcin = 0;
+            g.Cout = T; g.ldcout = K;
+            g.M = nbi; g.N = i0 - I0; g.kdim = i0 - I0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
+            int rc = qt_sgemm_tn(g, stream);
+            if (rc) return rc;
+            SgemmArgs t;
+            t.A = Dinv + (size_t)i * NB * NB; t.lda = NB;
+            t.B = T; t.ldb = K;
+            t.Cin = nullptr; t.ldcin = 0;
+            t.Cout = Y + (size_t)i0 * K + I0; t.ldcout = K;
+            t.M = nbi; t.N = i0 - I0; t.kdim = nbi; t.k_mode = SG_K_FULL; t.mode = SG_MODE_NEG;
+            rc = qt_sgemm_tn(t, stream);
+            if (rc) return rc;
+        }
+        if (I0 == 0) continue;
+        // left of the diagonal block: the K^3/3 of the inverse, one product per block row
         SgemmArgs g;
-        g.A = A + i0; g.lda = K;
+        g.A = A + I0; g.lda = K;
         g.B = Y; g.ldb = K;
         g.Cin = nullptr; g.ldcin = 0;
-        g.Cout = T; g.ldcout = K;
-        g.M = nbi; g.N = i0; g.kdim = i0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
+        g.Cout = TI; g.ldcout = K;
+        g.M = Wi; g.N = I0; g.kdim = I0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
         g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
         int rc = qt_sgemm_tn(g, stream);
         if (rc) return rc;
+        hipLaunchKernelGGL(transpose_lower_block_kernel, dim3((Wi + 31) / 32, (Wi + 31) / 32), dim3(256), 0, stream,
+                           (const float*)(Y + (size_t)I0 * K + I0), (int64_t)K, Wi, XT, NBO);
+        QT_LAUNCH_CHECK();
         SgemmArgs t;
-        t.A = Dinv + (size_t)i * NB * NB; t.lda = NB;
-        t.B = T; t.ldb = K;
+        t.A = XT; t.lda = NBO;
+        t.B = TI; t.ldb = K;
         t.Cin = nullptr; t.ldcin = 0;
-        t.Cout = Y + (size_t)i0 * K; t.ldcout = K;
-        t.M = nbi; t.N = i0; t.kdim = nbi; t.k_mode = SG_K_FULL; t.mode = SG_MODE_NEG;
+        t.Cout = Y + (size_t)I0 * K; t.ldcout = K;
+        t.M = Wi; t.N = I0; t.kdim = Wi; t.k_mode = SG_K_FULL; t.mode = SG_MODE_NEG;
         rc = qt_sgemm_tn(t, stream);
         if (rc) return rc;
     }

@@ -29,6 +29,10 @@ struct SgemmArgs {
     // bit for bit what chain-many separate launches would leave in C, with C read and written once
     // (the GPTQ sweep's far update over several 128-column blocks).
     int chain_len = 0;
+    // M == N products of which only the upper triangle is wanted (the right-looking Cholesky update
+    // A[J1:, J1:] -= R^T R): tiles entirely below the diagonal are skipped.  Cin == Cout (in place) is
+    // allowed in every mode: a thread reads its C elements before it writes them and no other does.
+    int upper_only = 0;
     // internal (set by qt_sgemm_tn)
     int k_chunk = 0;
     int fast_interior = 1;

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (p.upper_only && m0 >= n0 + BN) return;   // every row of this tile lies below every column: not wanted
     const bool tile_inside = p.fast_interior && m0 + BM <= p.M && n0 + BN <= p.N;   // wave-uniform
 
     int k_begin = 0;
