@@ -7,10 +7,10 @@
 //     U = Ut^-1 = J R^-T J = flat-reverse(Y),   Y = R^-T (lower).
 // Cost 2/3 K^3 flops (vs 4/3 K^3) and every block recurrence below is a k-major "TN" product,
 // i.e. one fp32-MFMA kernel (sgemm_tn) serves the whole chain.  Two block sizes: NB = 128 for the
-// latency-bound panel kernels, NBO = 512 for everything that carries the K^3 work, so that work
+// latency-bound panel kernels, NBO = 256 for everything that carries the K^3 work, so that work
 // runs as a few dozen large GEMMs (k = 512, hundreds to thousands of 128x128 tiles, no split-K
 // slabs) instead of one M = 128 split-K product per 128 columns:
-//   potrf, RIGHT-looking over 512-wide outer blocks J, left-looking inside one (all in place in A):
+//   potrf, RIGHT-looking over NBO-wide outer blocks J, left-looking inside one (all in place in A):
 //     block row j of J :  A[j, j:] -= sum_{p in J, p<j} R[p, j]^T R[p, j:]   (sgemm SUB, k <= 384)
 //                         R_jj = chol(A_jj), 32x32 inverses                   (potf2_kernel)
 //                         R[j, j+1:] = R_jj^-T A[j, j+1:]                     (trsm_rt_kernel)
@@ -21,13 +21,26 @@
 //                         Y[i, I0:i] = -Dinv_i^T T ;  Y[i, i] = Dinv_i^T     (k <= 384)
 //     left of I        :  T_I = sum_{p<I0} R[p, I]^T Y[p, :I0]               (sgemm SET, k = I0)
 //                         Y[I, :I0] = -Y_II T_I = -(Y_II^T)^T T_I             (transpose + sgemm NEG, k = 512)
+#include <stdlib.h>
+
 #include "common.h"
 #include "sgemm_tn.h"
 
 namespace {
 
 constexpr int NB = 128;
-constexpr int NBO = 512;     // outer block of the K^3 work
+constexpr int NBO_MAX = 1024; // workspace is sized for the widest outer block
+// outer block of the K^3 work (a multiple of 128; QT_CHOL_NBO for A/B runs; measured at K = 14336 / 4096:
+// 128: 40.5 / 4.30 ms, 256: 35.3 / 4.04, 512: 36.4 / 4.05, 1024: 38.5 / 4.40)
+static int chol_nbo() {
+    static const int v = [] {
+        const char* e = getenv("QT_CHOL_NBO");
+        int x = e ? atoi(e) : 256;
+        x = x / 128 * 128;
+        return x < 128 ? 128 : (x > NBO_MAX ? NBO_MAX : x);
+    }();
+    return v;
+}
 constexpr int LDP = NB + 1;  // padded LDS leading dimension
 
 // ---- panel kernels --------------------------------------------------------------------------
@@ -403,8 +416,9 @@ extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
     const size_t nb = (K + NB - 1) / NB;
     // T panel [128, K] + T_I panel [512, K] + X_II [512, 512] + Rd, Dinv [nb][128*128] each + split-K slabs
     // (a split product writes splits * M * N floats with splits <= 2048 workgroups / tiles: <= 2048 * 128 * 128)
-    const size_t split = (size_t)2048 * NB * NB * 4 + (size_t)NBO * K * 4;
-    return (size_t)NB * K * 4 + (size_t)NBO * K * 4 + (size_t)NBO * NBO * 4 + nb * (NB * NB + RD_STRIDE) * 4 + split + 256;
+    const size_t split = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
+    return (size_t)NB * K * 4 + (size_t)NBO_MAX * K * 4 + (size_t)NBO_MAX * NBO_MAX * 4 +
+           nb * (NB * NB + RD_STRIDE) * 4 + split + 256;
 }
 
 extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
@@ -420,11 +434,12 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
     float* T = (float*)ws;
     float* TI = T + (size_t)NB * K;
-    float* XT = TI + (size_t)NBO * K;
-    float* Rd = XT + (size_t)NBO * NBO;
+    const int NBO = chol_nbo();
+    float* XT = TI + (size_t)NBO_MAX * K;
+    float* Rd = XT + (size_t)NBO_MAX * NBO_MAX;
     float* Dinv = Rd + (size_t)nblk * RD_STRIDE;
     float* split_ws = Dinv + (size_t)nblk * NB * NB;
-    const size_t split_ws_bytes = (size_t)2048 * NB * NB * 4 + (size_t)NBO * K * 4;
+    const size_t split_ws_bytes = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
     float* Y = U;
     const size_t inv_lds = (size_t)(NB * LDT + NB * LDP) * sizeof(float);
     const size_t potf2_lds = (size_t)(NB * LDA + 4 * 32 * 32) * sizeof(float);
