@@ -58,6 +58,7 @@ struct XtxParams {
     float* G;
     int map_mode;   // 0: rounds of 256 with XCD-contiguous blocks of 32; 1: identity
     int wrap_units; // > 0: timing-only locality ablation (xtx_kernel<true>)
+    unsigned* progress;  // [rounds][256] progress words of the direct items (zeroed per launch), or null
 };
 
 // LDS-DMA from inline asm: hipcc does not track it, so it inserts no vmcnt drain in front of later
@@ -79,6 +80,17 @@ __device__ __forceinline__ void glds16_pair(unsigned voffA, unsigned voffB, cons
         : "v"(voffA), "v"(voffB), "s"(sbase), "s"(ldsA), "s"(ldsB)
         : "memory");
 }
+__device__ __forceinline__ void glds16_snapshot(unsigned voff, const void* sbase, unsigned lds_dst) {
+    // 1 KiB of progress words -> LDS scratch; sc1: served by L2, never by this CU's L1 copy of the line
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1 sc1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
 __device__ __forceinline__ s16x8 tr_load8(const char* lds_addr) {
     // two transposing reads: tokens +0..3 and +4..7 (rows are 256 B apart -> +1024 B)
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS s16x4*)(lds_addr));
@@ -104,11 +116,25 @@ __device__ __forceinline__ void wait_vmcnt() {
 // WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
 // pointer wraps every wrap_units units, so the footprint every workgroup streams is that window --
 // L2-resident for small windows, Infinity-Cache-resident for medium ones (profiles/r02_xtx_locality.md).
-template <bool WRAP, bool F16>
+//
+// THROTTLE (speed only, never correctness): the 256 workgroups of a round stream the same ~32 panels.
+// While they stay within a few thousand tokens of each other, a panel missed by one XCD's L2 is in the
+// 256 MiB Infinity Cache for the other seven; once they drift apart it comes from HBM, and the chip
+// -- power-limited in this kernel -- lowers its clock (profiles/r02_xtx_locality_sweep.txt: 1.31 PF with
+// HBM-served misses, 1.43-1.50 with on-die ones).  Every THR_CHK units wave 0 of a direct item
+// publishes its unit index and snapshots the round's 256 progress words (one 1 KiB LDS-DMA, read
+// THR_CHK units later, when the counted vmcnt has long retired it); a workgroup more than THR_WIN
+// units ahead of the slowest STARTED, unfinished member sleeps a bounded while (its other waves wait
+// at the phase barrier).  No workgroup ever waits FOR another: no spin, no dependence on residency.
+constexpr int THR_CHK = 32;
+constexpr int THR_WIN = 192;
+
+template <bool WRAP, bool F16, bool THROTTLE>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     constexpr int LEAD = 6;     // unit u+LEAD is issued in phase u  (LEAD <= RING-2, see the hazard analysis)
-    // ONE LDS object: the ring.  Unit image: [4 channel groups: A-lo, A-hi, B-lo, B-hi][16 tokens][256 B].
-    __shared__ __attribute__((aligned(16))) char ring[RING * UNIT_BYTES];
+    // ONE LDS object: the ring (+ 1 KiB of scratch for the throttle's progress snapshot).
+    // Unit image: [4 channel groups: A-lo, A-hi, B-lo, B-hi][16 tokens][256 B].
+    __shared__ __attribute__((aligned(16))) char ring[RING * UNIT_BYTES + (THROTTLE ? 1024 : 0)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,6 +219,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         }
     };
 
+    // ---- throttle state (wave 0 of a direct item only) ----
+    unsigned* prog_round = nullptr;
+    int prog_member = 0;
+    if (THROTTLE && p.progress && slab_idx < 0) {
+        prog_round = p.progress + (size_t)(logical >> 8) * 256;
+        prog_member = logical & 255;
+    }
+    const bool throttled = THROTTLE && prog_round != nullptr && wave == 0;   // wave-uniform
+    bool snap_pending = false;
+    auto throttle_step = [&](int u) {
+        if (snap_pending) {
+            // the snapshot issued THR_CHK units ago: 4 progress words per lane (0 = not started)
+            const unsigned* sp = (const unsigned*)(ring + RING * UNIT_BYTES) + lane * 4;
+            unsigned m = 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned v = sp[e];
+                m = (v != 0 && v < m) ? v : m;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned o = (unsigned)__shfl_xor((int)m, off);
+                m = o < m ? o : m;
+            }
+            const int slowest = (int)__builtin_amdgcn_readfirstlane(m);     // 0x7fffffff: finished members
+            const int lag = (u - THR_CHK + 1) - slowest;                      // in units, at snapshot time
+            if (lag > THR_WIN) {
+                int naps = (lag - THR_WIN) / 24 + 1;                          // one nap ~ 8 k cycles ~ 20 units
+                naps = naps > 6 ? 6 : naps;
+                for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        if (lane == 0) {
+            unsigned* dst = prog_round + prog_member;
+            const unsigned val = (unsigned)(u + 1);
+            asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+        }
+        glds16_snapshot((unsigned)lane * 16u, prog_round, ring_lds + RING * UNIT_BYTES);
+        snap_pending = true;
+    };
+
     // ---- fragment read geometry (per lane), byte offsets inside a unit ----
     const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
     const int rowpart = (8 * (g >> 1) + q) * 256 + 32 * (g & 1) + 8 * pp;
@@ -269,6 +336,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         __builtin_amdgcn_sched_barrier(0);
     };
     auto body8 = [&](auto steady_c, int u) {
+        if (THROTTLE && throttled && (u & (THR_CHK - 1)) == 0) throttle_step(u);
         phase(std::integral_constant<int, 0>{}, steady_c, u);
         phase(std::integral_constant<int, 1>{}, steady_c, u + 1);
         phase(std::integral_constant<int, 2>{}, steady_c, u + 2);
@@ -304,6 +372,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         }
         if (!group_b) __builtin_amdgcn_s_barrier();  // pairs with group B's last barrier
         wait_vmcnt<0>();
+        if (THROTTLE && throttled && lane == 0) {   // finished: never the slowest member again
+            unsigned* dst = prog_round + prog_member;
+            const unsigned val = 0x7fffffffu;
+            asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+        }
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
@@ -373,7 +446,7 @@ __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict
 struct XtxPlan {
     int n_tiles, n_tt, has_tail;
     int n_direct, n_rem, s2;
-    size_t slab_bytes, tail_bytes, tab_bytes;
+    size_t slab_bytes, tail_bytes, tab_bytes, prog_bytes;
 };
 
 // Lower-triangular tiles in locality order: bands of 16 tile rows, 16x16 macro blocks along a
@@ -425,6 +498,7 @@ XtxPlan xtx_plan(int64_t n_tokens, int K) {
     pl.slab_bytes = (size_t)pl.s2 * pl.n_rem * BT * BT * 4;
     pl.tail_bytes = pl.has_tail ? qt_align_up((size_t)BKT * K * 2, 256) : 0;
     pl.tab_bytes = qt_align_up((size_t)pl.n_tiles * 4, 256);
+    pl.prog_bytes = qt_align_up((size_t)((pl.n_tiles + NUM_CU - 1) / NUM_CU) * 256 * sizeof(unsigned), 256);
     return pl;
 }
 
@@ -451,7 +525,7 @@ const int* xtx_host_table(int K, int n_tiles) {
 extern "C" size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K) {
     if (n_tokens <= 0 || K <= 0) return 0;
     XtxPlan pl = xtx_plan(n_tokens, K);
-    return pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
+    return pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + pl.prog_bytes + 256;
 }
 
 extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, float* G,
@@ -467,7 +541,7 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
     // per-lane source offsets are 32-bit: 16 token rows of one unit must span < 4 GiB
     QT_CHECK_ARG((uint64_t)ldx * 2 * UT + (uint64_t)K * 2 < ((uint64_t)1 << 32), "qt_xtx_accumulate: ldx too large");
     XtxPlan pl = xtx_plan(n_tokens, K);
-    const size_t need = pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + 256;
+    const size_t need = pl.slab_bytes + pl.tail_bytes + pl.tab_bytes + pl.prog_bytes + 256;
     if (workspace_bytes < need || !workspace) {
         qt_set_error("qt_xtx_accumulate: workspace %zu < required %zu", workspace_bytes, need);
         return QT_ERR_WORKSPACE;
@@ -502,6 +576,7 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
         const char* e = getenv("QT_XTX_MAP");
         p.map_mode = e ? atoi(e) : 0;
     }
+    p.progress = nullptr;
     {
         const char* e = getenv("QT_XTX_ABLATE_WRAP");  // timing-only ablation, see xtx_kernel<true>
         p.wrap_units = e ? atoi(e) : 0;
@@ -513,12 +588,31 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
         QT_HIP(hipMemcpy2DAsync(tail, (size_t)K * 2, (const char*)X + (size_t)full * ldx * 2, (size_t)ldx * 2,
                                 (size_t)K * 2, (size_t)tail_rows, hipMemcpyDeviceToDevice, stream));
     }
+    const char* thr_env = getenv("QT_XTX_THROTTLE");
+    const bool throttle_on = thr_env ? atoi(thr_env) != 0 : true;
+    unsigned* progress_ws = (unsigned*)(ws + pl.slab_bytes + pl.tail_bytes + pl.tab_bytes);
     auto launch = [&](const XtxParams& q, const XtxPlan& ql) -> int {
         const int grid = ql.n_direct + ql.n_rem * ql.s2;
         qt_prof_mark(QT_PROF_XTX, stream);
-        if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false>), dim3(grid), dim3(NTHREADS), 0, stream, q);
-        else if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true>), dim3(grid), dim3(NTHREADS), 0, stream, q);
-        else hipLaunchKernelGGL((xtx_kernel<false, false>), dim3(grid), dim3(NTHREADS), 0, stream, q);
+        // the throttle pays where several rounds of long items stream more than the Infinity Cache holds
+        XtxParams qq = q;
+        const bool thr = throttle_on && ql.n_direct >= 2 * NUM_CU && q.n_tt >= 512 &&
+                         (size_t)q.n_tt * BKT * (size_t)q.K * 2 > ((size_t)200 << 20);
+        if (thr) {
+            const size_t rounds = (size_t)(ql.n_direct + NUM_CU - 1) / NUM_CU;
+            if (hipMemsetAsync(progress_ws, 0, rounds * 256 * sizeof(unsigned), stream) != hipSuccess) {
+                qt_set_error("qt_xtx_accumulate: hipMemsetAsync(progress) failed");
+                return QT_ERR_HIP;
+            }
+            qq.progress = progress_ws;
+        } else {
+            qq.progress = nullptr;
+        }
+        if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+        else if (thr && x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+        else if (thr) hipLaunchKernelGGL((xtx_kernel<false, false, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+        else if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+        else hipLaunchKernelGGL((xtx_kernel<false, false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         qt_prof_mark(QT_PROF_XTX, stream);
         QT_LAUNCH_CHECK();
         if (ql.n_rem > 0) {

@@ -22,15 +22,16 @@ from quantool_amd.hip import ops
 DEV = torch.device("cuda:0")
 VARIANTS = {
     "ring": {},
+    "nothrottle": {"QT_XTX_THROTTLE": "0"},
     "ring_map1": {"QT_XTX_MAP": "1"},
     "wrap8": {"QT_XTX_ABLATE_WRAP": "8"},          # timing-only ablations (wrong results)
     "wrap64": {"QT_XTX_ABLATE_WRAP": "64"},
 }
-CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "ring,ring_map1").split(",") if v]
+CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "ring,nothrottle").split(",") if v]
 
 
 def setenv(v):
-    for k in ("QT_XTX_MAP", "QT_XTX_ABLATE_WRAP"):
+    for k in ("QT_XTX_MAP", "QT_XTX_ABLATE_WRAP", "QT_XTX_THROTTLE"):
         os.environ.pop(k, None)
     os.environ.update(VARIANTS[v])
 
