@@ -59,6 +59,8 @@ struct XtxParams {
     int map_mode;   // 0: rounds of 256 with XCD-contiguous blocks of 32; 1: identity
     int wrap_units; // > 0: timing-only locality ablation (xtx_kernel<true>)
     unsigned* progress;  // [rounds][256] progress words of the direct items (zeroed per launch), or null
+    int thr_win;         // throttle: units a workgroup may lead the slowest started member by
+    int thr_nap;         // throttle: s_sleep argument of one nap (x64 cycles)
 };
 
 // LDS-DMA from inline asm: hipcc does not track it, so it inserts no vmcnt drain in front of later
@@ -123,11 +125,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // -- power-limited in this kernel -- lowers its clock (profiles/r02_xtx_locality_sweep.txt: 1.31 PF with
 // HBM-served misses, 1.43-1.50 with on-die ones).  Every THR_CHK units wave 0 of a direct item
 // publishes its unit index and snapshots the round's 256 progress words (one 1 KiB LDS-DMA, read
-// THR_CHK units later, when the counted vmcnt has long retired it); a workgroup more than THR_WIN
+// THR_CHK units later, when the counted vmcnt has long retired it); a workgroup more than thr_win
 // units ahead of the slowest STARTED, unfinished member sleeps a bounded while (its other waves wait
 // at the phase barrier).  No workgroup ever waits FOR another: no spin, no dependence on residency.
 constexpr int THR_CHK = 32;
-constexpr int THR_WIN = 192;
 
 template <bool WRAP, bool F16, bool THROTTLE>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
@@ -245,10 +246,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
             }
             const int slowest = (int)__builtin_amdgcn_readfirstlane(m);     // 0x7fffffff: finished members
             const int lag = (u - THR_CHK + 1) - slowest;                      // in units, at snapshot time
-            if (lag > THR_WIN) {
-                int naps = (lag - THR_WIN) / 24 + 1;                          // one nap ~ 8 k cycles ~ 20 units
+            if (lag > p.thr_win) {
+                int naps = (lag - p.thr_win) / 24 + 1;                        // one nap of 127 ~ 8 k cycles ~ 20 units
                 naps = naps > 6 ? 6 : naps;
-                for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+                for (int i = 0; i < naps; ++i) {
+                    if (p.thr_nap >= 96) __builtin_amdgcn_s_sleep(127);
+                    else if (p.thr_nap >= 48) __builtin_amdgcn_s_sleep(64);
+                    else __builtin_amdgcn_s_sleep(32);
+                }
             }
         }
         if (lane == 0) {
@@ -577,6 +582,8 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
         p.map_mode = e ? atoi(e) : 0;
     }
     p.progress = nullptr;
+    p.thr_win = 128;
+    p.thr_nap = 127;
     {
         const char* e = getenv("QT_XTX_ABLATE_WRAP");  // timing-only ablation, see xtx_kernel<true>
         p.wrap_units = e ? atoi(e) : 0;
@@ -596,8 +603,9 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
         qt_prof_mark(QT_PROF_XTX, stream);
         // the throttle pays where several rounds of long items stream more than the Infinity Cache holds
         XtxParams qq = q;
-        const bool thr = throttle_on && ql.n_direct >= 2 * NUM_CU && q.n_tt >= 512 &&
-                         (size_t)q.n_tt * BKT * (size_t)q.K * 2 > ((size_t)200 << 20);
+        // (measured: K = 14336, 6 rounds, 5.6 GB of X: +3...4 %; K = 8192, 2 rounds: -1 %)
+        const bool thr = throttle_on && ql.n_direct >= 4 * NUM_CU && q.n_tt >= 512 &&
+                         (size_t)q.n_tt * BKT * (size_t)q.K * 2 > ((size_t)1 << 30);
         if (thr) {
             const size_t rounds = (size_t)(ql.n_direct + NUM_CU - 1) / NUM_CU;
             if (hipMemsetAsync(progress_ws, 0, rounds * 256 * sizeof(unsigned), stream) != hipSuccess) {
@@ -605,6 +613,10 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
                 return QT_ERR_HIP;
             }
             qq.progress = progress_ws;
+            static const int win = [] { const char* e = getenv("QT_XTX_THR_WIN"); return e ? atoi(e) : 128; }();
+            static const int nap = [] { const char* e = getenv("QT_XTX_THR_NAP"); return e ? atoi(e) : 127; }();
+            qq.thr_win = win;
+            qq.thr_nap = nap;
         } else {
             qq.progress = nullptr;
         }
