@@ -312,7 +312,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kept.append(step(_))
-    t_enqueued = time.perf_counter() - t0      # host side done issuing; the device is still working
     join_streams(dev)
     if dist is not None:
         # final gather of the packed state to rank 0 (the job's only collective)
@@ -389,7 +388,7 @@ def main():
             "metric": ("quantized weights/sec (GPTQ int4, Llama-3-8B, 512 calib samples)" if not awq else
                        "quantized weights/sec (AWQ int4, Llama-3-8B, 512 calib samples) [BASELINE.json configs[2], not the headline]"),
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {
@@ -413,7 +412,7 @@ def main():
 def pmc_traffic():
     """HBM bytes per xtx_kernel launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes
     over this same workload, committed under profiles/); bench.py cannot run the profiler itself."""
-    f = ROOT / "profiles" / "r01_xtx_pmc_traffic.json"
+    f = ROOT / "profiles" / "r02_xtx_pmc_traffic.json"
     try:
         return float(json.loads(f.read_text())["avg_bytes_per_launch_over_a_step"])
     except Exception:

@@ -322,6 +322,8 @@ def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = N
                              dataloader=calibration_dataloader, dataset_path=dataset_path, text_column=text_column,
                              trust_remote_code=trust_remote_code_model, seed=seed, precision=precision,
                              sequential_targets=sequential_targets)
+    # scratch buffers are cached per (device, stream, purpose) while a job runs: give them back now
+    ops.release_workspaces()
     if output_dir:
         from .sharding import dist_world
 
