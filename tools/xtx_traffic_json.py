@@ -15,7 +15,10 @@ for K, d in ((4096, sys.argv[1]), (14336, sys.argv[2])):
         for row in csv.DictReader(open(f)):
             if "xtx_kernel" in row["Kernel_Name"]:
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    per = {k: sum(x for x in v if x > 0.5 * max(v)) / len([x for x in v if x > 0.5 * max(v)]) for k, v in vals.items()}
+    per = {}
+    for k, v in vals.items():
+        big = [x for x in v if x > 0.5 * max(v)] or v      # the full launches (the first one is a short warm-up)
+        per[k] = sum(big) / len(big)
     fetch = per["FETCH_SIZE"] * 1024 * 2
     write = per["WRITE_SIZE"] * 1024
     alg = N * K * 2 + K * K * 4
