@@ -417,6 +417,224 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pipeline on v_mfma_f32_16x16x32_{bf16,f16} (QT_XTX_SHAPE=16).  The chip is power-limited in
+// this kernel and can hold a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per
+// flop (guide, DVFS give-back item 7), so the shape is decided by wall time, not by cycles.
+// k = 32 tokens per MFMA, so a PHASE consumes a pair of units ("double": 32 tokens, 32 KiB) and the ring
+// grows to 10 units = 5 doubles (160 KiB: all of the CU's LDS, the throttle scratch reuses nothing).
+// Lane groups 0,1 of a fragment read tokens 0-15 from the first unit of the pair, groups 2,3 tokens
+// 16-31 from the second; inside a 32-lane half the two groups read token rows r and r+8 of one unit,
+// so the source-side swizzle also folds token-row bit 3 into the chunk index (conflict-free: the 32
+// lanes of a half then cover all 16 chunks x 2 halves of a 256-byte bank row exactly once).
+//   RAW / WAR: as above with "unit" := double, 5 slots, LEAD 3 doubles: two doubles (8 LDS-DMA
+//   instructions per wave, 64 KiB per CU) stay in flight behind a counted vmcnt(8).
+constexpr int RING16 = 10;          // units
+constexpr int DBL_BYTES = 2 * UNIT_BYTES;
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
+    constexpr int ND = 5;       // doubles resident in LDS
+    constexpr int LEAD = 3;     // double d+LEAD is issued in phase d  (LEAD <= ND-2)
+    __shared__ __attribute__((aligned(16))) char ring[RING16 * UNIT_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2, wave_n = wave & 3;
+    const bool group_b = wave >= 4;
+
+    int logical;
+    {
+        const int b = blockIdx.x, nwg = gridDim.x;
+        if (p.map_mode == 0) {
+            const int round = b >> 8, rb = b & 255;
+            const int m = min(256, nwg - (round << 8));
+            const int xcd = rb & 7, idx = rb >> 3, q8 = m >> 3, r8 = m & 7;
+            logical = (round << 8) + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        } else {
+            logical = b;
+        }
+    }
+    int tile_idx, tt0, cnt, slab_idx = -1;
+    if (logical < p.n_direct) {
+        tile_idx = logical;
+        tt0 = 0;
+        cnt = p.n_tt;
+    } else {
+        const int l2 = logical - p.n_direct;
+        const int chunk = l2 / p.n_rem;
+        tile_idx = p.n_direct + (l2 - chunk * p.n_rem);
+        const int base_cnt = p.n_tt / p.s2, rem = p.n_tt % p.s2;
+        tt0 = chunk * base_cnt + (chunk < rem ? chunk : rem);
+        cnt = base_cnt + (chunk < rem ? 1 : 0);
+        slab_idx = l2;
+    }
+    const int tt_packed = p.tile_tab[tile_idx];
+    const int ti = tt_packed >> 16, tj = tt_packed & 0xFFFF;
+    const int nd = cnt * (BKT / (2 * UT));  // doubles of this item (2 per 64-token tile)
+    const int K = p.K;
+    const size_t ld2 = (size_t)p.ldx * 2;
+
+    // staging: as xtx_kernel, with token-row bit 3 folded into the chunk swizzle
+    const int rsub = lane >> 4;
+    const int row_hi = (wave & 3) >> 1;                                  // bit 3 of the token row inside the unit
+    const int lch = (lane & 15) ^ (rsub << 2) ^ (row_hi << 1);
+    const int trow = 4 * (wave & 3) + rsub;
+    int colA = ti * BT + (wave >> 2) * 128 + lch * 8;
+    int colB = tj * BT + (wave >> 2) * 128 + lch * 8;
+    colA = colA > K - 8 ? K - 8 : colA;
+    colB = colB > K - 8 ? K - 8 : colB;
+    const unsigned voffA = (unsigned)((size_t)trow * ld2 + (size_t)colA * 2);
+    const unsigned voffB = (unsigned)((size_t)trow * ld2 + (size_t)colB * 2);
+    const unsigned ring_lds = (unsigned)(size_t)(QT_LDS char*)ring;
+    const unsigned dst_wave = __builtin_amdgcn_readfirstlane(ring_lds + (wave >> 2) * 4096 + (wave & 3) * 1024);
+
+    const bool ends_in_tail = p.has_tail && (tt0 + cnt == p.n_tt);
+    const int d_tail = ends_in_tail ? nd - 2 : 0x7fffffff;             // first double taken from the staging
+    const size_t ustride = (size_t)UT * ld2;
+    auto dbl_src = [&](int d) -> const char* {
+        return d >= d_tail ? (const char*)p.tail + (size_t)(d - d_tail) * 2 * ustride
+                           : (const char*)p.X + ((size_t)tt0 * BKT + (size_t)d * 2 * UT) * ld2;
+    };
+    const char* run_src = (const char*)p.X + (size_t)tt0 * BKT * ld2;
+    auto issue_at = [&](const char* src, int slot) {
+        const unsigned d0 = dst_wave + (unsigned)slot * DBL_BYTES;
+        glds16_pair(voffA, voffB, src, d0, d0 + 8192);
+        glds16_pair(voffA, voffB, src + ustride, d0 + UNIT_BYTES, d0 + UNIT_BYTES + 8192);
+    };
+
+    // fragment geometry: lane group g = lane >> 4 takes tokens 8g..8g+7 of the double
+    const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
+    const int swz = ((q << 1) ^ (g & 1)) & 7;                            // XOR on the 16-channel block index
+    const int lane_base = (g >> 1) * UNIT_BYTES + (8 * (g & 1) + q) * 256 + 16 * (pp >> 1) + 8 * (pp & 1);
+    int aoff[8], boff[4];
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) aoff[ai] = wave_m * 4096 + lane_base + 32 * (ai ^ swz);
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj)
+        boff[bj] = (2 + (wave_n >> 1)) * 4096 + lane_base + 32 * ((((wave_n & 1) << 2) + bj) ^ swz);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ai][bj][r] = 0.0f;
+
+    s16x8 fa[8], fb[4];
+    auto drain_wait = [&](int d) {
+        const int later = nd - d - 2;      // doubles after d+1 that exist
+        if (later >= 2) wait_vmcnt<8>();
+        else if (later == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+    };
+    auto phase = [&](auto slot_c, auto steady_c, int d) {
+        constexpr int S = decltype(slot_c)::value;
+        constexpr bool STEADY = decltype(steady_c)::value;
+        constexpr int ISLOT = (S + LEAD) % ND;
+        const char* base = ring + S * DBL_BYTES;
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) fa[ai] = tr_load8(base + aoff[ai]);
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) fb[bj] = tr_load8(base + boff[bj]);
+        if (STEADY) {
+            issue_at(run_src, ISLOT);
+            run_src += 2 * ustride;
+            wait_vmcnt<8>();        // everything up to double d+1 has landed; 2 doubles stay in flight
+        } else if (d + LEAD < nd) {
+            issue_at(dbl_src(d + LEAD), ISLOT);
+            wait_vmcnt<8>();
+        } else {
+            drain_wait(d);
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) acc[ai][bj] = mfma32<F16>(fa[ai], fb[bj], acc[ai][bj]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nd > 0) {
+#pragma unroll
+        for (int i = 0; i < LEAD; ++i)
+            if (i < nd) issue_at(dbl_src(i), i);
+        if (nd >= LEAD) wait_vmcnt<4 * (LEAD - 1)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (group_b) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        const int steady_end = (nd < d_tail ? nd : d_tail);
+        run_src += (size_t)LEAD * 2 * ustride;
+        int d = 0;
+        for (; d + ND + LEAD <= steady_end; d += ND) {
+            phase(std::integral_constant<int, 0>{}, std::true_type{}, d);
+            phase(std::integral_constant<int, 1>{}, std::true_type{}, d + 1);
+            phase(std::integral_constant<int, 2>{}, std::true_type{}, d + 2);
+            phase(std::integral_constant<int, 3>{}, std::true_type{}, d + 3);
+            phase(std::integral_constant<int, 4>{}, std::true_type{}, d + 4);
+        }
+        // d is a multiple of 5 here: the remaining phases take slots 0, 1, 2, ... in turn
+        for (; d < nd; d += ND) {
+            phase(std::integral_constant<int, 0>{}, std::false_type{}, d);
+            if (d + 1 < nd) phase(std::integral_constant<int, 1>{}, std::false_type{}, d + 1);
+            if (d + 2 < nd) phase(std::integral_constant<int, 2>{}, std::false_type{}, d + 2);
+            if (d + 3 < nd) phase(std::integral_constant<int, 3>{}, std::false_type{}, d + 3);
+            if (d + 4 < nd) phase(std::integral_constant<int, 4>{}, std::false_type{}, d + 4);
+        }
+        if (!group_b) __builtin_amdgcn_s_barrier();
+        wait_vmcnt<0>();
+    }
+
+    // epilogue: 16x16 tiles, lane = column (B channel), registers = 4 consecutive rows (A channels)
+    const int jl = lane & 15, ih = 4 * (lane >> 4);
+    if (slab_idx < 0) {
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) {
+                const int gj = tj * BT + wave_n * 64 + bj * 16 + jl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = ti * BT + wave_m * 128 + ai * 16 + ih + r;
+                    if (gi < K && gj < K) {
+                        float* dst = p.G + (size_t)gi * K + gj;
+                        *dst = *dst + acc[ai][bj][r];
+                    }
+                }
+            }
+    } else {
+        float* slab = p.slabs + (size_t)slab_idx * (size_t)(BT * BT);
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i_loc = wave_m * 128 + ai * 16 + ih + r;
+                    const int j_loc = wave_n * 64 + bj * 16 + jl;
+                    slab[i_loc * BT + j_loc] = acc[ai][bj][r];
+                }
+    }
+}
+
 // G[tile] += sum_s slab[s][tile]  (ascending s; one float4 per thread per step) for the split tiles
 __global__ __launch_bounds__(256) void xtx_reduce_kernel(const float* __restrict__ slabs, int n_rem, int n_splits,
                                                          float* __restrict__ G, int K,
@@ -620,7 +838,13 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
         } else {
             qq.progress = nullptr;
         }
-        if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+        const char* she = getenv("QT_XTX_SHAPE");
+        const bool shape16 = she && atoi(she) == 16;
+        if (shape16 && q.wrap_units == 0) {
+            qq.progress = nullptr;
+            if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx16_kernel<true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+            else hipLaunchKernelGGL((xtx16_kernel<false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+        } else if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         else if (thr && x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         else if (thr) hipLaunchKernelGGL((xtx_kernel<false, false, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         else if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);

@@ -23,6 +23,7 @@ DEV = torch.device("cuda:0")
 VARIANTS = {
     "ring": {},
     "nothrottle": {"QT_XTX_THROTTLE": "0"},
+    "shape16": {"QT_XTX_SHAPE": "16"},
     "ring_map1": {"QT_XTX_MAP": "1"},
     "wrap8": {"QT_XTX_ABLATE_WRAP": "8"},          # timing-only ablations (wrong results)
     "wrap64": {"QT_XTX_ABLATE_WRAP": "64"},
@@ -31,7 +32,7 @@ CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "ring,nothrottle").spli
 
 
 def setenv(v):
-    for k in ("QT_XTX_MAP", "QT_XTX_ABLATE_WRAP", "QT_XTX_THROTTLE"):
+    for k in ("QT_XTX_MAP", "QT_XTX_ABLATE_WRAP", "QT_XTX_THROTTLE", "QT_XTX_SHAPE"):
         os.environ.pop(k, None)
     os.environ.update(VARIANTS[v])
 
