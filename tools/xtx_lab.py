@@ -24,6 +24,7 @@ VARIANTS = {
     "ring": {},
     "nothrottle": {"QT_XTX_THROTTLE": "0"},
     "shape16": {"QT_XTX_SHAPE": "16"},
+    "shape16_nothr": {"QT_XTX_SHAPE": "16", "QT_XTX_THROTTLE": "0"},
     "ring_map1": {"QT_XTX_MAP": "1"},
     "wrap8": {"QT_XTX_ABLATE_WRAP": "8"},          # timing-only ablations (wrong results)
     "wrap64": {"QT_XTX_ABLATE_WRAP": "64"},
