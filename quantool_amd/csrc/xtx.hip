@@ -418,11 +418,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same pipeline on v_mfma_f32_16x16x32_{bf16,f16} (QT_XTX_SHAPE=16).  The chip is power-limited in
+// The same pipeline on v_mfma_f32_16x16x32_{bf16,f16} (the default wherever the throttle is not in play;
+// QT_XTX_SHAPE=16|32 forces a shape).  The chip is power-limited in
 // this kernel and can hold a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per
 // flop (guide, DVFS give-back item 7), so the shape is decided by wall time, not by cycles.
 // k = 32 tokens per MFMA, so a PHASE consumes a pair of units ("double": 32 tokens, 32 KiB) and the ring
-// grows to 10 units = 5 doubles (160 KiB: all of the CU's LDS, the throttle scratch reuses nothing).
+// grows to 10 units = 5 doubles (160 KiB: all of the CU's LDS, so this variant carries no throttle --
+// a register-snapshot form of it was built and measured slower, -1 % at K = 14336).
 // Lane groups 0,1 of a fragment read tokens 0-15 from the first unit of the pair, groups 2,3 tokens
 // 16-31 from the second; inside a 32-lane half the two groups read token rows r and r+8 of one unit,
 // so the source-side swizzle also folds token-row bit 3 into the chunk index (conflict-free: the 32
@@ -440,40 +442,9 @@ __device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// Throttle (see xtx_kernel): LDS is full here, so the progress snapshot (4 words per lane) goes to
-// registers.  The load, the phase's four LDS-DMA instructions and a counted wait sit in ONE asm
-// statement (hipcc sees the outputs only after the wait): vmcnt(4) leaves exactly this phase's DMA in
-// flight, i.e. once per 16 phases wave 0 waits for one double more than the steady vmcnt(8) does.
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-__device__ __forceinline__ u32x4 glds16_double_with_snapshot(unsigned voffA, unsigned voffB, const void* src0,
-                                                             const void* src1, unsigned lds0, unsigned snap_voff,
-                                                             const void* prog) {
-    u32x4 snap;
-    asm volatile(
-        "global_load_dwordx4 %0, %7, %8 sc1\n\t"
-        "s_mov_b32 m0, %5\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %3\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %4\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %4\n\t"
-        "s_waitcnt vmcnt(4)"
-        : "=&v"(snap)
-        : "v"(voffA), "v"(voffB), "s"(src0), "s"(src1), "s"(lds0), "s"(0), "v"(snap_voff), "s"(prog)
-        : "memory", "scc");
-    return snap;
-}
-
-template <bool F16, bool THROTTLE>
+template <bool F16>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
     constexpr int ND = 5;       // doubles resident in LDS
-    constexpr int THR_CHK_D = 16;   // doubles between two progress checks (= 32 units)
     constexpr int LEAD = 3;     // double d+LEAD is issued in phase d  (LEAD <= ND-2)
     __shared__ __attribute__((aligned(16))) char ring[RING16 * UNIT_BYTES];
     const int tid = threadIdx.x;
@@ -542,40 +513,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
         glds16_pair(voffA, voffB, src + ustride, d0 + UNIT_BYTES, d0 + UNIT_BYTES + 8192);
     };
 
-    unsigned* prog_round = nullptr;
-    int prog_member = 0;
-    if (THROTTLE && p.progress && slab_idx < 0) {
-        prog_round = p.progress + (size_t)(logical >> 8) * 256;
-        prog_member = logical & 255;
-    }
-    const bool throttled = THROTTLE && prog_round != nullptr && wave == 0;   // wave-uniform
-    // steady issue of double d+LEAD by wave 0 in a check phase: snapshot, decide, nap, publish (progress in doubles)
-    auto issue_and_throttle = [&](const char* src, int slot, int d) {
-        const unsigned d0 = dst_wave + (unsigned)slot * DBL_BYTES;
-        const u32x4 v = glds16_double_with_snapshot(voffA, voffB, src, src + ustride, d0, (unsigned)lane * 16u, prog_round);
-        unsigned m = 0xffffffffu;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m = (v[e] != 0 && v[e] < m) ? v[e] : m;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned o = (unsigned)__shfl_xor((int)m, off);
-            m = o < m ? o : m;
-        }
-        const int slowest = (int)__builtin_amdgcn_readfirstlane(m);
-        const int lag = (d + 1) - slowest;                      // in doubles
-        const int win = p.thr_win >> 1;
-        if (lag > win) {
-            int naps = (lag - win) / 12 + 1;
-            naps = naps > 6 ? 6 : naps;
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-        if (lane == 0) {
-            unsigned* dst = prog_round + prog_member;
-            const unsigned val = (unsigned)(d + 1);
-            asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
-        }
-    };
-
     // fragment geometry: lane group g = lane >> 4 takes tokens 8g..8g+7 of the double
     const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
     const int swz = ((q << 1) ^ (g & 1)) & 7;                            // XOR on the 16-channel block index
@@ -612,8 +549,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
 #pragma unroll
         for (int bj = 0; bj < 4; ++bj) fb[bj] = tr_load8(base + boff[bj]);
         if (STEADY) {
-            if (THROTTLE && throttled && (d & (THR_CHK_D - 1)) == 0) issue_and_throttle(run_src, ISLOT, d);
-            else issue_at(run_src, ISLOT);
+            issue_at(run_src, ISLOT);
             run_src += 2 * ustride;
             wait_vmcnt<8>();        // everything up to double d+1 has landed; 2 doubles stay in flight
         } else if (d + LEAD < nd) {
@@ -667,11 +603,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
         }
         if (!group_b) __builtin_amdgcn_s_barrier();
         wait_vmcnt<0>();
-        if (THROTTLE && throttled && lane == 0) {   // finished: never the slowest member again
-            unsigned* dst = prog_round + prog_member;
-            const unsigned val = 0x7fffffffu;
-            asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
-        }
     }
 
     // epilogue: 16x16 tiles, lane = column (B channel), registers = 4 consecutive rows (A channels)
@@ -909,13 +840,15 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
         } else {
             qq.progress = nullptr;
         }
+        // MFMA shape: 16x16x32 where the throttle is not in play (+2...3 % at K = 4096 on every box tried;
+        // at K = 14336 it ranged +0.5...+6 % unthrottled, and the throttled 32x32x16 ring beat it);
+        // QT_XTX_SHAPE=16|32 forces one (same-process A/B: tools/xtx_lab.py)
         const char* she = getenv("QT_XTX_SHAPE");
-        const bool shape16 = she && atoi(she) == 16;
+        const bool shape16 = she ? atoi(she) == 16 : !thr;
         if (shape16 && q.wrap_units == 0) {
-            if (thr && x_dtype == QT_F16) hipLaunchKernelGGL((xtx16_kernel<true, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
-            else if (thr) hipLaunchKernelGGL((xtx16_kernel<false, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
-            else if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx16_kernel<true, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
-            else hipLaunchKernelGGL((xtx16_kernel<false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+            qq.progress = nullptr;
+            if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx16_kernel<true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+            else hipLaunchKernelGGL((xtx16_kernel<false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         } else if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         else if (thr && x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         else if (thr) hipLaunchKernelGGL((xtx_kernel<false, false, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);

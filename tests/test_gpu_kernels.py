@@ -75,6 +75,23 @@ def test_xtx_split_tiles_strided_and_ragged(ops, oracle, dev, n_tokens, K, pad):
     assert np.all(np.abs(got - 2 * np.tril(Gt)) <= 2e-5 * np.tril(np.outer(d, d)) + 1e-30)
 
 
+@pytest.mark.parametrize("shape", ["16", "32"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_xtx_both_mfma_shapes(ops, dev, monkeypatch, shape, dtype):
+    """The Gram kernel exists on two MFMA shapes (16x16x32 by default, the 32x32x16 ring with the progress
+    throttle for many-round launches); QT_XTX_SHAPE forces one, so both are covered whatever the default."""
+    monkeypatch.setenv("QT_XTX_SHAPE", shape)
+    g = torch.Generator(device=dev).manual_seed(int(shape))
+    for n, K in ((777, 264), (4096 + 5, 1280), (300, 4352)):
+        X = torch.randn((n, K), generator=g, device=dev).to(dtype)
+        G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+        ops.xtx_accumulate(X, G)
+        ops.xtx_accumulate(X, G)
+        want = 2 * torch.tril(X.double().t() @ X.double())
+        d = torch.sqrt(torch.diag(want) / 2)
+        assert bool(((torch.tril(G).double() - want).abs() <= 2e-5 * torch.tril(torch.outer(d, d)) + 1e-30).all())
+
+
 def test_per_sample_staging_matches_single_launch(ops, oracle, dev):
     """The plugin path's calling pattern (reference base.py:161: one sample per batch) goes through the
     accumulator's device token buffer; the result must be the Gram sum a single launch gives (the

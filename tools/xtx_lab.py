@@ -21,15 +21,15 @@ from quantool_amd.hip import ops
 
 DEV = torch.device("cuda:0")
 VARIANTS = {
-    "ring": {},
-    "nothrottle": {"QT_XTX_THROTTLE": "0"},
+    "default": {},
+    "ring": {"QT_XTX_SHAPE": "32"},
+    "nothrottle": {"QT_XTX_SHAPE": "32", "QT_XTX_THROTTLE": "0"},
     "shape16": {"QT_XTX_SHAPE": "16"},
-    "shape16_nothr": {"QT_XTX_SHAPE": "16", "QT_XTX_THROTTLE": "0"},
     "ring_map1": {"QT_XTX_MAP": "1"},
     "wrap8": {"QT_XTX_ABLATE_WRAP": "8"},          # timing-only ablations (wrong results)
     "wrap64": {"QT_XTX_ABLATE_WRAP": "64"},
 }
-CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "ring,nothrottle").split(",") if v]
+CHECKED = [v for v in os.environ.get("XTX_LAB_VARIANTS", "default,ring,shape16").split(",") if v]
 
 
 def setenv(v):
@@ -155,7 +155,7 @@ def staged(K=14336, n=196608, T=384):
     """Per-sample accumulation through HessianAccumulator's token staging vs one launch."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator
 
-    setenv("ring")
+    setenv("default")
     X = synth(n, K, seed=K + 1)
     one = HessianAccumulator(K, DEV, stage_tokens=0)
     st = HessianAccumulator(K, DEV)
