@@ -93,3 +93,16 @@ def test_down_proj_row_slice_bit_exact_given_gpu_factor(dev, oracle):
     o = oracle.quantize_weight(Wf, H, actorder="static", U_override=U)
     assert np.array_equal(keep["perm"].cpu().numpy(), o["perm"].astype(np.int32))
     _assert_bit_exact(oracle, res, o, K, "static")
+
+
+def test_llama3_70b_k8192_row_slice_bit_exact_given_gpu_factor(dev, oracle):
+    """Config 4's K = 8192 groups (Llama-3-70B hidden size: q/k/v/o and gate/up inputs): a 192-row slice,
+    asymmetric + actorder = group, against the oracle with the GPU's 8192 x 8192 factor.  (The K = 28672
+    group runs in test_gpu_edges.py; the 8-rank split of both is planned in test_sharding_gloo.py.)"""
+    R, K = 192, 8192
+    Wf, res, keep, Gfull, n = _gpu_run(dev, R, K, n_samples=48, T=384, seed=19, actorder="group", symmetric=False)
+    H = oracle.hessian_from_gram_f32(Gfull, n)
+    del Gfull
+    o = oracle.quantize_weight(Wf, H, actorder="group", symmetric=False, U_override=keep["U"].cpu().numpy())
+    assert np.array_equal(keep["perm"].cpu().numpy(), o["perm"].astype(np.int32))
+    _assert_bit_exact(oracle, res, o, K, "group")

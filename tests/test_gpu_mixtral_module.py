@@ -77,3 +77,31 @@ def test_gptq_plugin_quantises_every_expert_on_its_routed_tokens(dev, oracle, tm
     # the fused parameter now holds the dequantised experts
     fused = model.model.layers[0].mlp.experts.experts[2].gate_up_proj.weight
     assert torch.equal(fused.data, res[f"{pre}2.gate_up_proj"].dequantized(torch.bfloat16))
+
+
+def test_smoothquant_plugin_on_tiny_mixtral(dev, tmp_path, monkeypatch):
+    """BASELINE config 5's recipe (SmoothQuant + GPTQ, W8A8) on the nn.Module path of a sparse-MoE model:
+    the attention inputs are smoothed against the input norm (norm / s, W * s), every expert Linear is
+    quantised to int8 channel-wise on its routed tokens, and the function stays close."""
+    import quantool_amd.methods  # noqa: F401
+    from quantool_amd.core import QuantizerRegistry
+
+    monkeypatch.chdir(tmp_path)
+    model = _tiny_mixtral(dev)
+    x = torch.randint(0, 512, (1, 32), device=dev)
+    with torch.no_grad():
+        before = model(input_ids=x).logits.float()
+    norm_before = model.model.layers[0].input_layernorm.weight.data.clone()
+    g = torch.Generator().manual_seed(4)
+    data = [{"input_ids": torch.randint(0, 512, (64,), generator=g)} for _ in range(8)]
+    q = QuantizerRegistry.create("smoothquant", model_id="synthetic/tiny-mixtral")
+    q.quantize(model=model, level="W8A8", dataset=data, num_calibration_samples=8, max_seq_length=64)
+    torch.cuda.synchronize()
+    assert not torch.equal(model.model.layers[0].input_layernorm.weight.data, norm_before)      # norm /= s
+    res = model._qt_results
+    assert len(res) == 2 * (4 + 2 * 4)
+    r = res["model.layers.1.mlp.experts.experts.3.down_proj"]
+    assert r.weight_packed is None and r.weight_q.dtype == torch.int8 and r.weight_scale.shape == (256, 1)
+    with torch.no_grad():
+        after = model(input_ids=x).logits.float()
+    assert float((after - before).norm() / before.norm()) < 0.1
