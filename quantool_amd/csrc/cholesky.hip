@@ -136,19 +136,25 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp,
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
         float* Akk = As + (32 * kb) * LDA + 32 * kb;
-        // ---- (i) diagonal sub-block: factor + inverse, wave 0, lanes 0..31 = columns ----
+        // ---- (i) diagonal sub-block: factor AND inverse in one pass, wave 0 ----
+        // Lanes 0..31 hold the columns of the 32x32 block, lanes 32..63 the columns of an identity.  One
+        // right-looking step c -- rcj = col[c] / r_cc on every lane, then col[i] -= R[c][i] * rcj for i > c
+        // with R[c][i] broadcast from lane i -- is the Cholesky step on the left half and the forward
+        // substitution R^T Z = I on the right half: the same instructions, so Z = R^-T (= X^T) costs no
+        // second 32-step loop.  Afterwards lane j < 32 holds R[i][j] in col[i], lane 32 + j holds X[j][c] in col[c].
         if (wave == 0) {
             float col[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) col[i] = Akk[i * LDA + l31];
+            for (int i = 0; i < 32; ++i) col[i] = (lane < 32) ? Akk[i * LDA + l31] : (i == l31 ? 1.0f : 0.0f);
 #pragma unroll
             for (int c = 0; c < 32; ++c) {
                 float piv = readlane_f(col[c], c);
                 const bool isbad = !(piv > 0.0f);
                 bad = (isbad && bad == 0 && 32 * kb + c < n) ? 32 * kb + c + 1 : bad;
                 piv = isbad ? 1.0f : piv;
-                const float rs = __builtin_amdgcn_rsqf(piv);
-                const float rcj = col[c] * rs;           // R[c][j] on lane j (j >= c meaningful)
+                float rs = __builtin_amdgcn_rsqf(piv);
+                rs = rs * fmaf(-0.5f * piv * rs, rs, 1.5f);   // one Newton step: the inverse inherits rs
+                const float rcj = col[c] * rs;           // R[c][j] on lane j, Z[c][j] = X[j][c] on lane 32 + j
                 col[c] = rcj;
 #pragma unroll
                 for (int i = c + 1; i < 32; ++i) {
@@ -157,30 +163,13 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp,
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // X = R_kk^-1: lane j owns column j of X; column p of R lives on lane p
-            float x[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) x[i] = (i == l31) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int p = 31; p >= 0; --p) {
-                const float rpp = readlane_f(col[p], p);
-                float rinv = __builtin_amdgcn_rcpf(rpp);
-                rinv = fmaf(fmaf(-rpp, rinv, 1.0f), rinv, rinv);
-                const float xp = x[p] * rinv;
-                x[p] = xp;
-#pragma unroll
-                for (int i = 0; i < p; ++i) {
-                    const float rip = readlane_f(col[i], p);
-                    x[i] = fmaf(-rip, xp, x[i]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (lane < 32) {
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    Akk[i * LDA + l31] = (i <= l31) ? col[i] : 0.0f;    // R_kk, zeros below diagonal
-                    Xs[(kb * 32 + i) * 32 + l31] = (i <= l31) ? x[i] : 0.0f;
-                }
+                for (int i = 0; i < 32; ++i) Akk[i * LDA + l31] = (i <= l31) ? col[i] : 0.0f;   // R_kk, zeros below
+            } else {
+                // lane 32 + j = row j of X = R_kk^-1 (upper): Xs[b][k = j][i = c] = X[j][c]
+#pragma unroll
+                for (int c = 0; c < 32; ++c) Xs[(kb * 32 + l31) * 32 + c] = (c >= l31) ? col[c] : 0.0f;
             }
         }
         __syncthreads();
