@@ -87,7 +87,8 @@ __device__ __forceinline__ void mma32_tn(const float* A, int lda, const float* B
 // P and Rout may be the same block (the factorisation runs in place): no __restrict__ on them.
 __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp, int n,
                                                     float* Rout, int64_t ldr,
-                                                    float* __restrict__ Rd, int32_t* info, int col0) {
+                                                    float* __restrict__ Rd, int32_t* info, int col0, int prio) {
+    qt_set_chain_prio(prio);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* As = sm;                // [NB][LDA]
     float* Xs = sm + NB * LDA;     // [4][32][32]  Xs[b][k][i] = X_b[k][i]
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp,
 // B and Z may be the same panel (in place: a thread reads its columns before it writes them).
 __global__ __launch_bounds__(256) void trsm_rt_kernel(const float* __restrict__ Rd, int n,
                                                       const float* B, int64_t ldb,
-                                                      float* Z, int64_t ldz, int ncols) {
+                                                      float* Z, int64_t ldz, int ncols, int prio) {
+    qt_set_chain_prio(prio);
     extern __shared__ __attribute__((aligned(16))) float Rs[];  // [RD_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < RD_STRIDE / 4; e += 256) ((f32x4*)Rs)[e] = ((const f32x4*)Rd)[e];
@@ -445,6 +447,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         return e;
     }));
     QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), stream));
+    const int prio = qt_chain_prio();
 
     // ---- A = R^T R: right-looking over 512-wide outer blocks, left-looking inside one; in place ----
     for (int J0 = 0; J0 < K; J0 += NBO) {
@@ -464,13 +467,13 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
                 if (rc) return rc;
             }
             hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), potf2_lds, stream, (const float*)Ajj, (int64_t)K, nbj,
-                               Ajj, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0);
+                               Ajj, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0, prio);
             QT_LAUNCH_CHECK();
             const int rest = K - j0 - nbj;
             if (rest > 0) {
                 hipLaunchKernelGGL(trsm_rt_kernel, dim3((rest + 127) / 128), dim3(256), RD_STRIDE * sizeof(float),
                                    stream, (const float*)(Rd + (size_t)j * RD_STRIDE), nbj, (const float*)(Ajj + nbj),
-                                   (int64_t)K, Ajj + nbj, (int64_t)K, rest);
+                                   (int64_t)K, Ajj + nbj, (int64_t)K, rest, prio);
                 QT_LAUNCH_CHECK();
             }
         }

@@ -52,6 +52,17 @@ void qt_prof_mark(int kernel_id, hipStream_t stream);  // no-op unless qt_profil
 
 static inline size_t qt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Wave priority of the latency-bound chain kernels (sweep block, panel factor, panel solve): their
+// sparse dependent instruction streams lose issue arbitration to co-resident MFMA-dense waves that run
+// their clusters at s_setprio 1; raised, a chain step runs closer to its stand-alone time while the
+// dense kernels lose almost no issue slots.  QT_CHAIN_PRIO=0..3 (read per call, for A/B runs).
+int qt_chain_prio();
+__device__ __forceinline__ void qt_set_chain_prio(int prio) {
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+}
+
 // Per-device, thread-safe "do once": kernel attributes (dynamic LDS size) belong to a device, and
 // the entry points may be called from several host threads (one per stream).  Usage:
 //   static QtOncePerDevice once;  QT_HIP(once.run([&] { return hipFuncSetAttribute(...); }));

@@ -32,7 +32,9 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
                                                            const float* __restrict__ zp_t,
                                                            const int32_t* __restrict__ g_idx, int i1, int cnt,
                                                            float qmin, float qmax, int8_t* __restrict__ Qt,
-                                                           float* __restrict__ ErrT, float* __restrict__ loss) {
+                                                           float* __restrict__ ErrT, float* __restrict__ loss,
+                                                           int prio) {
+    qt_set_chain_prio(prio);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Un = sm;                  // [BS][BS]   Un[i][j] = U[i1+i][i1+j], zero outside j>=i / cnt
     float* wl = sm + BS * BS;        // [BS cols][ROWS]
@@ -226,6 +228,7 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
         const int b = e ? atoi(e) : 4;
         return b < 1 ? 1 : (b > SWEEP_MAX_BATCH ? SWEEP_MAX_BATCH : b);
     }();
+    const int prio = qt_chain_prio();
     for (int b0 = 0; b0 < K; b0 += BS * batch_blocks) {
         const int bend = (b0 + BS * batch_blocks < K) ? b0 + BS * batch_blocks : K;   // first column right of the batch
         for (int i1 = b0; i1 < bend; i1 += BS) {
@@ -234,7 +237,7 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
             float* err_blk = ErrT + (size_t)(i1 - b0) * R;
             qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
             hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R,
-                               K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss);
+                               K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio);
             qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
             QT_LAUNCH_CHECK();
             if (i2 < bend) {   // near update: the rest of this batch
