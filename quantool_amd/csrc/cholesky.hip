@@ -41,6 +41,17 @@ static int chol_nbo() {
     }();
     return v;
 }
+// block rows of the inverse phase: its big product has M = this many rows, so wider rows mean fewer,
+// squarer GEMMs (QT_CHOL_NBI for A/B runs)
+static int chol_nbi() {
+    static const int v = [] {
+        const char* e = getenv("QT_CHOL_NBI");
+        int x = e ? atoi(e) : 256;
+        x = x / 128 * 128;
+        return x < 128 ? 128 : (x > NBO_MAX ? NBO_MAX : x);
+    }();
+    return v;
+}
 constexpr int LDP = NB + 1;  // padded LDS leading dimension
 
 // ---- panel kernels --------------------------------------------------------------------------
@@ -495,9 +506,10 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     hipLaunchKernelGGL(trinv_batched_kernel, dim3(nblk), dim3(NB), inv_lds, stream, (const float*)Rd, K, Dinv, Y,
                        (int64_t)K);
     QT_LAUNCH_CHECK();
-    // ---- Y = R^-T by 512-row block rows ----
-    for (int I0 = 0; I0 < K; I0 += NBO) {
-        const int I1 = (K - I0 < NBO) ? K : I0 + NBO;
+    // ---- Y = R^-T by NBI-row block rows ----
+    const int NBI = chol_nbi();
+    for (int I0 = 0; I0 < K; I0 += NBI) {
+        const int I1 = (K - I0 < NBI) ? K : I0 + NBI;
         const int Wi = I1 - I0;
         // the diagonal 512-block Y_II by the 128-row recurrence (short k)
         for (int i0 = I0 + NB; i0 < I1; i0 += NB) {
@@ -531,10 +543,10 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         int rc = qt_sgemm_tn(g, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(transpose_lower_block_kernel, dim3((Wi + 31) / 32, (Wi + 31) / 32), dim3(256), 0, stream,
-                           (const float*)(Y + (size_t)I0 * K + I0), (int64_t)K, Wi, XT, NBO);
+                           (const float*)(Y + (size_t)I0 * K + I0), (int64_t)K, Wi, XT, NBO_MAX);
         QT_LAUNCH_CHECK();
         SgemmArgs t;
-        t.A = XT; t.lda = NBO;
+        t.A = XT; t.lda = NBO_MAX;
         t.B = TI; t.ldb = K;
         t.Cin = nullptr; t.ldcin = 0;
         t.Cout = Y + (size_t)I0 * K; t.ldcout = K;
