@@ -11,7 +11,7 @@ import sys
 trace, bench = sys.argv[1], sys.argv[2]
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-rows = [r for r in csv.DictReader(open(trace)) if "xtx_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(trace)) if "xtx" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 a, b = 4 * warm, 4 * (warm + steps)
