@@ -365,7 +365,7 @@ def main():
         alg_bytes += sum(20 * (R * K * 2 + K * K * 4) for _, K, lins in shape.groups for _, R in lins) * args.steps
     achieved_tflops = alg_flops / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else 0.0
     roofline = {
-        "kernel": "xtx_kernel", "bound": "mfma", "achieved": round(achieved_tflops, 2),
+        "kernel": "xtx_kernel / xtx16_kernel (the Gram kernel on its two MFMA shapes)", "bound": "mfma", "achieved": round(achieved_tflops, 2),
         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
         "traffic": pmc_traffic(),
         "launches": int(launches.value), "avg_launch_ms": round(tot_ms.value / max(1, launches.value), 4),

@@ -61,6 +61,7 @@ struct XtxParams {
     unsigned* progress;  // [rounds][256] progress words of the direct items (zeroed per launch), or null
     int thr_win;         // throttle: units a workgroup may lead the slowest started member by
     int thr_nap;         // throttle: s_sleep argument of one nap (x64 cycles)
+    int thr_chk;         // throttle: units between two progress checks (8, 16 or 32)
 };
 
 // LDS-DMA from inline asm: hipcc does not track it, so it inserts no vmcnt drain in front of later
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
                 m = o < m ? o : m;
             }
             const int slowest = (int)__builtin_amdgcn_readfirstlane(m);     // 0x7fffffff: finished members
-            const int lag = (u - THR_CHK + 1) - slowest;                      // in units, at snapshot time
+            const int lag = (u - p.thr_chk + 1) - slowest;                    // in units, at snapshot time
             if (lag > p.thr_win) {
                 int naps = (lag - p.thr_win) / 24 + 1;                        // one nap of 127 ~ 8 k cycles ~ 20 units
                 naps = naps > 6 ? 6 : naps;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         __builtin_amdgcn_sched_barrier(0);
     };
     auto body8 = [&](auto steady_c, int u) {
-        if (THROTTLE && throttled && (u & (THR_CHK - 1)) == 0) throttle_step(u);
+        if (THROTTLE && throttled && (u & (p.thr_chk - 1)) == 0) throttle_step(u);
         phase(std::integral_constant<int, 0>{}, steady_c, u);
         phase(std::integral_constant<int, 1>{}, steady_c, u + 1);
         phase(std::integral_constant<int, 2>{}, steady_c, u + 2);
@@ -804,6 +805,7 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
     p.progress = nullptr;
     p.thr_win = 128;
     p.thr_nap = 127;
+    p.thr_chk = 32;
     {
         const char* e = getenv("QT_XTX_ABLATE_WRAP");  // timing-only ablation, see xtx_kernel<true>
         p.wrap_units = e ? atoi(e) : 0;
@@ -837,6 +839,8 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
             static const int nap = [] { const char* e = getenv("QT_XTX_THR_NAP"); return e ? atoi(e) : 127; }();
             qq.thr_win = win;
             qq.thr_nap = nap;
+            static const int chk = [] { const char* e = getenv("QT_XTX_THR_CHK"); const int v = e ? atoi(e) : 32; return (v == 8 || v == 16 || v == 64 || v == 128 || v == 256) ? v : 32; }();
+            qq.thr_chk = chk;
         } else {
             qq.progress = nullptr;
         }
