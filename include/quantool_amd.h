@@ -192,6 +192,15 @@ int qt_sgemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, co
                     int64_t ldcin, float* Cout, int64_t ldcout, int M, int N, int kdim, int skip_zero_k,
                     int mode, int allow_split_k, void* workspace, size_t workspace_bytes, qt_stream_t stream);
 
+/* ---- fp32-accurate "TN" product on the bf16 MFMA (three bf16 planes per operand, six plane products;
+ * building block of a8's K^3 products; exposed for tests) ---------------------------------------
+ * A [k][lda], B [k][ldb] fp32, k a multiple of 128, M / N / lda / ldb multiples of 4.
+ * kind 0: C -= A^T B (one workgroup per 256x256 tile);  kind 1: C = A^T B, k split into slabs reduced in
+ * fixed order.  Not an ascending-k fmaf chain: never used where the oracle pins the order (a11). */
+size_t qt_gemm3_tn_f32_workspace_bytes(int M, int N, int k);
+int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                    int N, int k, int kind, void* workspace, size_t workspace_bytes, qt_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference surface) -------------
  * When enabled, HIP events are recorded on the launch stream immediately around the named
  * kernel; qt_profile_read synchronises them, returns the summed device time and the launch

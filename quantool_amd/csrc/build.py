@@ -70,7 +70,7 @@ def _compile(src: Path) -> Path:
 
 
 def audit_m0(src: Path) -> None:
-    """xtx.hip writes M0 from inline asm without restoring it (the LDS-DMA destination).  That is only
+    """xtx.hip and gemm3_tn.hip write M0 from inline asm without restoring it (the LDS-DMA destination).  That is only
     sound while hipcc itself never touches M0 in that translation unit, so the device ISA is checked:
     every line that names m0 must sit inside an ;;#ASMSTART ... ;;#ASMEND block."""
     stamp = OBJ_DIR / (src.stem + ".m0audit")
@@ -101,7 +101,8 @@ def build(verbose: bool = False) -> Path:
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
-    audit_m0(CSRC / "xtx.hip")
+    for name in ("xtx.hip", "gemm3_tn.hip"):
+        audit_m0(CSRC / name)
     newest = max(o.stat().st_mtime for o in objs)
     if not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH), *map(str, objs)]

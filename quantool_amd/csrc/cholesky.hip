@@ -22,8 +22,14 @@
 //     left of I        :  T_I = sum_{p<I0} R[p, I]^T Y[p, :I0]               (sgemm SET, k = I0)
 //                         Y[I, :I0] = -Y_II T_I = -(Y_II^T)^T T_I             (transpose + sgemm NEG, k = 512)
 #include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <tuple>
+#include <vector>
 
 #include "common.h"
+#include "gemm3_tn.h"
 #include "sgemm_tn.h"
 
 namespace {
@@ -52,6 +58,95 @@ static int chol_nbi() {
     }();
     return v;
 }
+// ---- bf16x3 block-row products (gemm3_tn.h) ---------------------------------------------------------
+// Where a block-row product of the chain has enough k-chunks to fill the chip with xtx-class items, it
+// runs on the bf16 MFMA from three-plane copies of R and Y (measured in the same process, k = 14080,
+// 256 x 14080 outputs: 0.53 ms vs 0.90 ms on the f32 MFMA; tools/gemm3_bench.py).  The factorisation is
+// then LEFT-looking at the outer level (block row J gathers  A[J, J:] -= R[:J0, J]^T R[:J0, J:]  in one
+// long-k product: each element of A is read and written once, where the right-looking k = 256 update of
+// the whole trailing matrix is bound by that read-modify-write), and the inverse's T_I product is the same
+// shape.  QT_CHOL_G3=0 disables; QT_CHOL_G3_MIN_CHUNKS = 128-row k-chunks a product needs (default 768 =
+// 3 per CU).  Item tables for every step are built once per (K, block sizes) in pinned host memory and
+// uploaded with one async copy per call.
+struct G3Step {
+    int n_items = 0, n_red = 0;
+    size_t item_off = 0, red_off = 0;   // bytes into the table blob
+};
+struct CholG3Plan {
+    bool any = false;
+    std::vector<G3Step> fac, inv;       // per outer block / per block row (n_items == 0: sgemm_tn)
+    char* blob = nullptr;               // pinned
+    size_t blob_bytes = 0;
+    int max_slabs = 0;
+};
+
+static int chol_g3_min_chunks() {   // read per call: tests switch the path on for small K
+    const char* on = getenv("QT_CHOL_G3");
+    if (on && atoi(on) == 0) return 0;
+    const char* e = getenv("QT_CHOL_G3_MIN_CHUNKS");
+    const int x = e ? atoi(e) : 768;
+    return x < 1 ? 1 : x;
+}
+
+static const CholG3Plan* chol_g3_plan(int K, int NBO, int NBI) {
+    static std::mutex m;
+    static std::map<std::tuple<int, int, int, int>, CholG3Plan*> plans;
+    const int min_chunks = chol_g3_min_chunks();
+    std::lock_guard<std::mutex> lock(m);
+    const auto key = std::make_tuple(K, NBO, NBI, min_chunks);
+    auto it = plans.find(key);
+    if (it != plans.end()) return it->second;
+    CholG3Plan* pl = new CholG3Plan();
+    std::vector<char> bytes;
+    auto add = [&](int Tm, int Tn, int c_end, int tri) {
+        G3Step st;
+        if (min_chunks <= 0 || K % 8 != 0 || g3_row_chunks(Tm, Tn, c_end, tri) < min_chunks) return st;
+        std::vector<G3Item> items;
+        std::vector<G3Red> red;
+        g3_plan_row(Tm, Tn, c_end, tri, items, red);
+        st.n_items = (int)items.size();
+        st.n_red = (int)red.size();
+        st.item_off = qt_align_up(bytes.size(), 256);
+        bytes.resize(st.item_off + items.size() * sizeof(G3Item));
+        memcpy(bytes.data() + st.item_off, items.data(), items.size() * sizeof(G3Item));
+        st.red_off = qt_align_up(bytes.size(), 256);
+        bytes.resize(st.red_off + red.size() * sizeof(G3Red));
+        if (!red.empty()) memcpy(bytes.data() + st.red_off, red.data(), red.size() * sizeof(G3Red));
+        for (const G3Red& r : red) pl->max_slabs = pl->max_slabs > r.first + r.count ? pl->max_slabs : r.first + r.count;
+        pl->any = true;
+        return st;
+    };
+    for (int J0 = 0; J0 < K; J0 += NBO) {
+        const int J1 = (K - J0 < NBO) ? K : J0 + NBO;
+        pl->fac.push_back(J0 == 0 ? G3Step() : add((J1 - J0 + 255) / 256, (K - J0 + 255) / 256, J0 / 128, 0));
+    }
+    for (int I0 = 0; I0 < K; I0 += NBI) {
+        const int I1 = (K - I0 < NBI) ? K : I0 + NBI;
+        pl->inv.push_back(I0 == 0 ? G3Step() : add((I1 - I0 + 255) / 256, (I0 + 255) / 256, I0 / 128, 1));
+    }
+    if (pl->any) {
+        pl->blob_bytes = qt_align_up(bytes.size(), 256);
+        if (hipHostMalloc((void**)&pl->blob, pl->blob_bytes, hipHostMallocDefault) != hipSuccess) {
+            pl->any = false;   // no pinned memory: stay on the f32 path
+            pl->blob = nullptr;
+        } else {
+            memcpy(pl->blob, bytes.data(), bytes.size());
+        }
+    }
+    if (!pl->any) {
+        pl->blob_bytes = 0;
+        pl->max_slabs = 0;
+        for (G3Step& st : pl->fac) st = G3Step();
+        for (G3Step& st : pl->inv) st = G3Step();
+    }
+    plans[key] = pl;
+    return pl;
+}
+static size_t chol_g3_ws_bytes(const CholG3Plan* pl, int K) {
+    if (!pl->any) return 0;
+    return 2 * qt_align_up((size_t)3 * K * K * 2, 256) + (size_t)pl->max_slabs * 256 * 256 * 4 + pl->blob_bytes + 256;
+}
+
 constexpr int LDP = NB + 1;  // padded LDS leading dimension
 
 // ---- panel kernels --------------------------------------------------------------------------
@@ -420,7 +515,7 @@ extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
     // (a split product writes splits * M * N floats with splits <= 2048 workgroups / tiles: <= 2048 * 128 * 128)
     const size_t split = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
     return (size_t)NB * K * 4 + (size_t)NBO_MAX * K * 4 + (size_t)NBO_MAX * NBO_MAX * 4 +
-           nb * (NB * NB + RD_STRIDE) * 4 + split + 256;
+           nb * (NB * NB + RD_STRIDE) * 4 + split + 256 + chol_g3_ws_bytes(chol_g3_plan(K, chol_nbo(), chol_nbi()), K);
 }
 
 extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
@@ -442,6 +537,47 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     float* Dinv = Rd + (size_t)nblk * RD_STRIDE;
     float* split_ws = Dinv + (size_t)nblk * NB * NB;
     const size_t split_ws_bytes = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
+    const int NBI = chol_nbi();
+    // bf16x3 products: plane copies of R and Y, slabs, item tables (only when some step uses them)
+    const CholG3Plan* g3 = chol_g3_plan(K, NBO, NBI);
+    unsigned short *Rpl = nullptr, *Ypl = nullptr;
+    float* g3_slabs = nullptr;
+    char* g3_tab = nullptr;
+    const int64_t plane_stride = (int64_t)K * K;
+    if (g3->any) {
+        char* q = (char*)qt_align_up((size_t)((char*)split_ws + split_ws_bytes), 256);
+        Rpl = (unsigned short*)q;
+        q += qt_align_up((size_t)3 * K * K * 2, 256);
+        Ypl = (unsigned short*)q;
+        q += qt_align_up((size_t)3 * K * K * 2, 256);
+        g3_slabs = (float*)q;
+        q += (size_t)g3->max_slabs * 256 * 256 * 4;
+        g3_tab = q;
+        QT_HIP(hipMemcpyAsync(g3_tab, g3->blob, g3->blob_bytes, hipMemcpyHostToDevice, stream));
+    }
+    auto g3_row = [&](const G3Step& st, const unsigned short* Bplanes, int col_a0, int col_b0, int M, int N, float* C,
+                      int mode) -> int {
+        G3Args a;
+        a.Apl = Rpl;
+        a.Bpl = Bplanes;
+        a.plane_stride = plane_stride;
+        a.ld = K;
+        a.rowA0 = a.rowB0 = 0;
+        a.colA0 = col_a0;
+        a.colB0 = col_b0;
+        a.colmax = K;
+        a.M = M;
+        a.N = N;
+        a.C = C;
+        a.ldc = K;
+        a.mode = mode;
+        a.slabs = g3_slabs;
+        a.items = (const G3Item*)(g3_tab + st.item_off);
+        a.n_items = st.n_items;
+        a.red = (const G3Red*)(g3_tab + st.red_off);
+        a.n_red = st.n_red;
+        return qt_gemm3_launch(a, stream);
+    };
     float* Y = U;
     const size_t inv_lds = (size_t)(NB * LDT + NB * LDP) * sizeof(float);
     const size_t potf2_lds = (size_t)(NB * LDA + 4 * 32 * 32) * sizeof(float);
@@ -460,9 +596,30 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), stream));
     const int prio = qt_chain_prio();
 
-    // ---- A = R^T R: right-looking over 512-wide outer blocks, left-looking inside one; in place ----
-    for (int J0 = 0; J0 < K; J0 += NBO) {
+    // ---- A = R^T R over NBO-wide outer blocks, left-looking inside one; in place.  Outer level: right-looking
+    // (one k = NBO update of the trailing matrix per block) on the f32 MFMA, or -- when the bf16x3 products
+    // are in use for this K -- left-looking (block row J gathers all earlier block rows in one long-k product)
+    for (int J0 = 0, Jb = 0; J0 < K; J0 += NBO, ++Jb) {
         const int J1 = (K - J0 < NBO) ? K : J0 + NBO;
+        if (g3->any && J0 > 0) {
+            // A[J, J0:] -= R[:J0, J]^T R[:J0, J0:]
+            const G3Step& st = g3->fac[Jb];
+            float* C = A + (size_t)J0 * K + J0;
+            if (st.n_items > 0) {
+                int rc = g3_row(st, Rpl, J0, J0, J1 - J0, K - J0, C, G3_SUB);
+                if (rc) return rc;
+            } else {
+                SgemmArgs g;
+                g.A = A + J0; g.lda = K;
+                g.B = A + J0; g.ldb = K;
+                g.Cin = C; g.ldcin = K;
+                g.Cout = C; g.ldcout = K;
+                g.M = J1 - J0; g.N = K - J0; g.kdim = J0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+                g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
+                int rc = qt_sgemm_tn(g, stream);
+                if (rc) return rc;
+            }
+        }
         for (int j0 = J0; j0 < J1; j0 += NB) {
             const int j = j0 / NB, nbj = (K - j0 < NB) ? K - j0 : NB;
             float* Ajj = A + (size_t)j0 * K + j0;
@@ -489,7 +646,15 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             }
         }
         const int rem = K - J1;
-        if (rem > 0) {
+        if (g3->any) {
+            // plane copies of the finished block row (columns from its diagonal block on; only entries above
+            // the diagonal are ever read back)
+            if (rem > 0) {
+                int rc = qt_split3_launch(A + (size_t)J0 * K + J0, K, J1 - J0, K - J0, Rpl + (size_t)J0 * K + J0, K,
+                                          plane_stride, 0, 0, 0, stream);
+                if (rc) return rc;
+            }
+        } else if (rem > 0) {
             // the K^3/3 of the factorisation: one SYRK-shaped update per outer block, upper tiles only
             SgemmArgs g;
             g.A = A + (size_t)J0 * K + J1; g.lda = K;
@@ -507,8 +672,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
                        (int64_t)K);
     QT_LAUNCH_CHECK();
     // ---- Y = R^-T by NBI-row block rows ----
-    const int NBI = chol_nbi();
-    for (int I0 = 0; I0 < K; I0 += NBI) {
+    for (int I0 = 0, Ib = 0; I0 < K; I0 += NBI, ++Ib) {
         const int I1 = (K - I0 < NBI) ? K : I0 + NBI;
         const int Wi = I1 - I0;
         // the diagonal 512-block Y_II by the 128-row recurrence (short k)
@@ -531,16 +695,30 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             rc = qt_sgemm_tn(t, stream);
             if (rc) return rc;
         }
-        if (I0 == 0) continue;
+        // plane copy of the finished block row of Y (zeros above the diagonal), for the later rows' products
+        auto split_row = [&]() -> int {
+            if (!g3->any || I1 >= K) return QT_OK;
+            return qt_split3_launch(Y + (size_t)I0 * K, K, Wi, I1, Ypl + (size_t)I0 * K, K, plane_stride, 1, I0, 0, stream);
+        };
+        if (I0 == 0) {
+            int rc0 = split_row();
+            if (rc0) return rc0;
+            continue;
+        }
         // left of the diagonal block: the K^3/3 of the inverse, one product per block row
-        SgemmArgs g;
-        g.A = A + I0; g.lda = K;
-        g.B = Y; g.ldb = K;
-        g.Cin = nullptr; g.ldcin = 0;
-        g.Cout = TI; g.ldcout = K;
-        g.M = Wi; g.N = I0; g.kdim = I0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
-        g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
-        int rc = qt_sgemm_tn(g, stream);
+        int rc;
+        if (g3->any && g3->inv[Ib].n_items > 0) {
+            rc = g3_row(g3->inv[Ib], Ypl, I0, 0, Wi, I0, TI, G3_SET);
+        } else {
+            SgemmArgs g;
+            g.A = A + I0; g.lda = K;
+            g.B = Y; g.ldb = K;
+            g.Cin = nullptr; g.ldcin = 0;
+            g.Cout = TI; g.ldcout = K;
+            g.M = Wi; g.N = I0; g.kdim = I0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
+            g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
+            rc = qt_sgemm_tn(g, stream);
+        }
         if (rc) return rc;
         hipLaunchKernelGGL(transpose_lower_block_kernel, dim3((Wi + 31) / 32, (Wi + 31) / 32), dim3(256), 0, stream,
                            (const float*)(Y + (size_t)I0 * K + I0), (int64_t)K, Wi, XT, NBO_MAX);
@@ -552,6 +730,8 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         t.Cout = Y + (size_t)I0 * K; t.ldcout = K;
         t.M = Wi; t.N = I0; t.kdim = Wi; t.k_mode = SG_K_FULL; t.mode = SG_MODE_NEG;
         rc = qt_sgemm_tn(t, stream);
+        if (rc) return rc;
+        rc = split_row();
         if (rc) return rc;
     }
     hipLaunchKernelGGL(flat_reverse_lower_to_upper_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, U, K);

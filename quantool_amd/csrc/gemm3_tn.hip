@@ -1,0 +1,451 @@
+// See gemm3_tn.h.  The kernel is xtx.hip's pipeline (unit = 16 k-rows x (256 A + 256 B columns) = 16 KiB,
+// ring of 8 units, LDS-DMA of unit u+6 issued in phase u behind a counted vmcnt(10), waves 4-7 one barrier
+// behind waves 0-3; hazard analysis at xtx_kernel) with two changes:
+//   * the A and B panels of a unit come from two plane sets, and the unit sequence of an item walks
+//     k-chunk (128 rows) -> plane product (6) -> 8 units, so one 8-phase body stays inside one plane pair;
+//   * the epilogue applies the tile to C (C -= acc / C = acc) or stores a slab for the ordered reduction.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "gemm3_tn.h"
+#include "ring_pipe.h"
+
+namespace {
+
+constexpr int BT = 256;
+constexpr int UT = 16;
+constexpr int UNIT_BYTES = UT * 2 * BT * 2;
+constexpr int RING = 8;
+constexpr int NTHREADS = 512;
+constexpr int NUM_CU = 256;
+constexpr int CH_ROWS = 128;                    // k rows per chunk
+constexpr int CH_UNITS = 6 * (CH_ROWS / UT);    // 48 units: 6 plane products x 8 units
+// plane (0 = hi, 1 = mid, 2 = lo) of the A / B operand in product pr, two bits each, smallest product first:
+//   pr:  0      1      2       3       4       5
+//   A :  lo     hi     mid     mid     hi      hi
+//   B :  hi     lo     mid     hi      mid     hi
+constexpr unsigned PA_BITS = 2u | (0u << 2) | (1u << 4) | (1u << 6) | (0u << 8) | (0u << 10);
+constexpr unsigned PB_BITS = 0u | (2u << 2) | (1u << 4) | (0u << 6) | (1u << 8) | (0u << 10);
+
+struct G3Params {
+    const char* Apl;
+    const char* Bpl;
+    int64_t plane_bytes;
+    int64_t ld2;          // row pitch in bytes
+    int64_t rowA0, rowB0;
+    int colA0, colB0, colmax;
+    int M, N;
+    float* C;
+    int64_t ldc;
+    float* slabs;
+    const G3Item* items;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
+    constexpr int LEAD = 6;
+    __shared__ __attribute__((aligned(16))) char ring[RING * UNIT_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 2, wave_n = wave & 3;
+    const bool group_b = wave >= 4;
+
+    const G3Item* itp = p.items + blockIdx.x;
+    const int it_tile = __builtin_amdgcn_readfirstlane(itp->tile);
+    const int c_lo = __builtin_amdgcn_readfirstlane(itp->c_lo);
+    const int c_hi = __builtin_amdgcn_readfirstlane(itp->c_hi);
+    const int slab_idx = __builtin_amdgcn_readfirstlane(itp->slab);
+    const int ti = it_tile >> 16, tj = it_tile & 0xFFFF;
+    const int nu = (c_hi - c_lo) * CH_UNITS;   // a multiple of 48
+
+    // staging geometry: as xtx_kernel (wave w fills k rows 4*(w&3)..+3 of column group w>>2; XOR swizzle of
+    // the 16-B chunk index on the SOURCE address)
+    const int rsub = lane >> 4;
+    const int lch = (lane & 15) ^ (rsub << 2);
+    const int trow = 4 * (wave & 3) + rsub;
+    int colA = p.colA0 + ti * BT + (wave >> 2) * 128 + lch * 8;
+    int colB = p.colB0 + tj * BT + (wave >> 2) * 128 + lch * 8;
+    colA = colA > p.colmax - 8 ? p.colmax - 8 : colA;   // edge tiles: clamp (masked at the store)
+    colB = colB > p.colmax - 8 ? p.colmax - 8 : colB;
+    const unsigned voffA = (unsigned)((size_t)trow * (size_t)p.ld2 + (size_t)colA * 2);
+    const unsigned voffB = (unsigned)((size_t)trow * (size_t)p.ld2 + (size_t)colB * 2);
+    const unsigned ring_lds = (unsigned)(size_t)(QT_LDS char*)ring;
+    const unsigned dst_wave =
+        __builtin_amdgcn_readfirstlane(ring_lds + (wave >> 2) * 4096 + (wave & 3) * 1024);
+
+    // unit i of the item -> (k chunk, plane product, 16-row slice): scalar source pointers of both panels
+    const int64_t ustride = (int64_t)UT * p.ld2;
+    auto unit_src = [&](int i, const char*& a, const char*& b) {
+        const int g = i >> 3, j = i & 7;
+        const int c = g / 6, pr = g - 6 * c;
+        const int64_t plA = (PA_BITS >> (2 * pr)) & 3u, plB = (PB_BITS >> (2 * pr)) & 3u;
+        const int64_t row = (int64_t)(c_lo + c) * CH_ROWS + j * UT;
+        a = p.Apl + plA * p.plane_bytes + (p.rowA0 + row) * p.ld2;
+        b = p.Bpl + plB * p.plane_bytes + (p.rowB0 + row) * p.ld2;
+    };
+    auto issue = [&](int i, int slot) {
+        const char *a, *b;
+        unit_src(i, a, b);
+        const unsigned d = dst_wave + (unsigned)slot * UNIT_BYTES;
+        glds16_pair2(voffA, voffB, a, b, d, d + 8192);
+    };
+    // steady state: running pointers; a body of 8 phases issues units u+6 .. u+13, the plane pair changes
+    // at unit u+8 (phase slot 2), where the pointers are recomputed
+    const char *runA = nullptr, *runB = nullptr;
+
+    // fragment read geometry: as xtx_kernel
+    const int g = lane >> 4, il = lane & 15, q = il >> 2, pp = il & 3;
+    const int rowpart = (8 * (g >> 1) + q) * 256 + 32 * (g & 1) + 8 * pp;
+    int aoff[4], boff[2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) aoff[mi] = wave_m * 4096 + rowpart + 64 * (mi ^ q);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+        boff[ni] = (2 + (wave_n >> 1)) * 4096 + rowpart + 64 * ((((wave_n & 1) << 1) + ni) ^ q);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    s16x8 fa[4], fb[2];
+    auto drain_wait = [&](int u) {
+        const int later = nu - u - 2;
+        if (later >= 5) wait_vmcnt<10>();
+        else if (later == 4) wait_vmcnt<8>();
+        else if (later == 3) wait_vmcnt<6>();
+        else if (later == 2) wait_vmcnt<4>();
+        else if (later == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+    auto phase = [&](auto slot_c, auto steady_c, int u) {
+        constexpr int S = decltype(slot_c)::value;
+        constexpr bool STEADY = decltype(steady_c)::value;
+        constexpr int ISLOT = (S + LEAD) & (RING - 1);
+        const char* base = ring + S * UNIT_BYTES;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = tr_load8(base + aoff[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[ni] = tr_load8(base + boff[ni]);
+        if (STEADY) {
+            if (S == 2) unit_src(u + LEAD, runA, runB);
+            const unsigned d = dst_wave + (unsigned)ISLOT * UNIT_BYTES;
+            glds16_pair2(voffA, voffB, runA, runB, d, d + 8192);
+            runA += ustride;
+            runB += ustride;
+            wait_vmcnt<10>();
+        } else if (u + LEAD < nu) {
+            issue(u + LEAD, ISLOT);
+            wait_vmcnt<10>();
+        } else {
+            drain_wait(u);
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = mfma16<false>(fa[mi], fb[ni], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto body8 = [&](auto steady_c, int u) {
+        phase(std::integral_constant<int, 0>{}, steady_c, u);
+        phase(std::integral_constant<int, 1>{}, steady_c, u + 1);
+        phase(std::integral_constant<int, 2>{}, steady_c, u + 2);
+        phase(std::integral_constant<int, 3>{}, steady_c, u + 3);
+        phase(std::integral_constant<int, 4>{}, steady_c, u + 4);
+        phase(std::integral_constant<int, 5>{}, steady_c, u + 5);
+        phase(std::integral_constant<int, 6>{}, steady_c, u + 6);
+        phase(std::integral_constant<int, 7>{}, steady_c, u + 7);
+    };
+
+    if (nu > 0) {
+#pragma unroll
+        for (int i = 0; i < LEAD; ++i) issue(i, i);   // nu >= 48 > LEAD
+        wait_vmcnt<2 * (LEAD - 1)>();
+        __builtin_amdgcn_s_barrier();
+        if (group_b) __builtin_amdgcn_s_barrier();   // stagger: group B runs one interval behind
+        __builtin_amdgcn_sched_barrier(0);
+        unit_src(LEAD, runA, runB);
+        int u = 0;
+        for (; u + 8 + LEAD <= nu; u += 8) body8(std::true_type{}, u);
+        for (; u + 8 <= nu; u += 8) body8(std::false_type{}, u);
+        if (!group_b) __builtin_amdgcn_s_barrier();   // pairs with group B's last barrier
+        wait_vmcnt<0>();
+    }
+
+    // ---- epilogue ----
+    const int jl = lane & 31, ih = 4 * (lane >> 5);
+    if (slab_idx < 0) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int gj = tj * BT + wave_n * 64 + ni * 32 + jl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = ti * BT + wave_m * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + ih;
+                    if (gi < p.M && gj < p.N) {
+                        float* dst = p.C + (size_t)gi * p.ldc + gj;
+                        if (MODE == G3_SUB) *dst = *dst - acc[mi][ni][r];
+                        else *dst = acc[mi][ni][r];
+                    }
+                }
+            }
+    } else {
+        float* slab = p.slabs + (size_t)slab_idx * (size_t)(BT * BT);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i_loc = wave_m * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + ih;
+                    const int j_loc = wave_n * 64 + ni * 32 + jl;
+                    slab[i_loc * BT + j_loc] = acc[mi][ni][r];
+                }
+    }
+}
+
+// C[tile] (-)= sum of the tile's slabs in table order (one float4 per thread per step)
+__global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restrict__ slabs,
+                                                           const G3Red* __restrict__ red, float* C, int64_t ldc,
+                                                           int M, int N, int mode) {
+    const G3Red t = red[blockIdx.x];
+    const int ti = t.tile >> 16, tj = t.tile & 0xFFFF;
+    const int part = blockIdx.y;   // 16 parts of 16 rows
+    const size_t tile_elems = (size_t)BT * BT;
+    for (int e = threadIdx.x; e < 16 * (BT / 4); e += blockDim.x) {
+        const int i_loc = part * 16 + e / (BT / 4);
+        const int j_loc = (e % (BT / 4)) * 4;
+        const int gi = ti * BT + i_loc, gj = tj * BT + j_loc;
+        if (gi >= M || gj >= N) continue;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < t.count; ++sp) {
+            const f32x4 v = *(const f32x4*)(slabs + (size_t)(t.first + sp) * tile_elems + (size_t)i_loc * BT + j_loc);
+            s += v;
+        }
+        float* dst = C + (size_t)gi * ldc + gj;
+        if (gj + 3 < N && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+            if (mode == G3_SUB) {
+                f32x4 o = *(f32x4*)dst;
+                o -= s;
+                *(f32x4*)dst = o;
+            } else {
+                *(f32x4*)dst = s;
+            }
+        } else {
+            for (int c = 0; c < 4 && gj + c < N; ++c) dst[c] = (mode == G3_SUB) ? dst[c] - s[c] : s[c];
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned short bf16_bits_rne(float v) {
+    return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int64_t ld_src, int cols,
+                                                     unsigned short* __restrict__ planes, int64_t ld_pl,
+                                                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0) {
+    const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int r = blockIdx.y;
+    if (c4 >= cols) return;
+    f32x4 v = *(const f32x4*)(src + (size_t)r * ld_src + c4);
+    typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+    u16x4 hi, mid, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (mask_upper && col_g0 + c4 + e > row_g0 + r) x = 0.0f;
+        const unsigned short h = bf16_bits_rne(x);
+        const float r1 = x - qt_bf16_to_f32(h);            // exact
+        const unsigned short m = bf16_bits_rne(r1);
+        const float r2 = r1 - qt_bf16_to_f32(m);           // exact
+        hi[e] = h;
+        mid[e] = m;
+        lo[e] = bf16_bits_rne(r2);
+    }
+    unsigned short* dst = planes + (size_t)r * ld_pl + c4;
+    *(u16x4*)dst = hi;
+    *(u16x4*)(dst + plane_stride) = mid;
+    *(u16x4*)(dst + 2 * plane_stride) = lo;
+}
+
+}  // namespace
+
+int qt_gemm3_launch(const G3Args& a, hipStream_t stream) {
+    if (a.n_items <= 0) return QT_OK;
+    QT_CHECK_ARG(a.ld % 8 == 0 && a.colmax >= 8, "qt_gemm3_launch: plane pitch %lld must be a multiple of 8", (long long)a.ld);
+    QT_CHECK_ARG(((uintptr_t)a.Apl & 15) == 0 && ((uintptr_t)a.Bpl & 15) == 0 && (a.plane_stride % 8) == 0,
+                 "qt_gemm3_launch: planes must be 16-byte aligned");
+    // per-lane source offsets are 32-bit: 16 rows of one unit must span < 4 GiB
+    QT_CHECK_ARG((uint64_t)a.ld * 2 * UT + (uint64_t)a.colmax * 2 < ((uint64_t)1 << 32), "qt_gemm3_launch: pitch too large");
+    G3Params p;
+    p.Apl = (const char*)a.Apl;
+    p.Bpl = (const char*)a.Bpl;
+    p.plane_bytes = a.plane_stride * 2;
+    p.ld2 = a.ld * 2;
+    p.rowA0 = a.rowA0;
+    p.rowB0 = a.rowB0;
+    p.colA0 = a.colA0;
+    p.colB0 = a.colB0;
+    p.colmax = a.colmax;
+    p.M = a.M;
+    p.N = a.N;
+    p.C = a.C;
+    p.ldc = a.ldc;
+    p.slabs = a.slabs;
+    p.items = a.items;
+    if (a.mode == G3_SUB) hipLaunchKernelGGL((gemm3_kernel<G3_SUB>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((gemm3_kernel<G3_SET>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
+    QT_LAUNCH_CHECK();
+    if (a.n_red > 0) {
+        hipLaunchKernelGGL(gemm3_reduce_kernel, dim3(a.n_red, 16), dim3(256), 0, stream, (const float*)a.slabs, a.red,
+                           a.C, a.ldc, a.M, a.N, a.mode);
+        QT_LAUNCH_CHECK();
+    }
+    return QT_OK;
+}
+
+int qt_split3_launch(const float* src, int64_t ld_src, int rows, int cols, unsigned short* planes, int64_t ld_pl,
+                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return QT_OK;
+    QT_CHECK_ARG(cols % 4 == 0 && ld_src % 4 == 0 && ld_pl % 4 == 0 && plane_stride % 4 == 0 &&
+                     ((uintptr_t)src & 15) == 0 && ((uintptr_t)planes & 7) == 0,
+                 "qt_split3_launch: columns / pitches must be multiples of 4 and the pointers aligned");
+    hipLaunchKernelGGL(split3_kernel, dim3((cols / 4 + 255) / 256, rows), dim3(256), 0, stream, src, ld_src, cols, planes,
+                       ld_pl, plane_stride, mask_upper, row_g0, col_g0);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+long g3_row_chunks(int Tm, int Tn, int c_end, int tri) {
+    long total = 0;
+    for (int tj = 0; tj < Tn; ++tj) total += (long)Tm * std::max(0, c_end - (tri ? 2 * tj : 0));
+    return total;
+}
+
+void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items, std::vector<G3Red>& red) {
+    items.clear();
+    red.clear();
+    const long total = g3_row_chunks(Tm, Tn, c_end, tri);
+    const int budget = std::max(1, NUM_CU - Tm * Tn);   // items <= total / per + tiles <= 256
+    int per = (int)((total + budget - 1) / budget);
+    per = std::max(per, 2);
+    int next_slab = 0;
+    for (int ti = 0; ti < Tm; ++ti)
+        for (int tj = 0; tj < Tn; ++tj) {
+            const int lo = tri ? 2 * tj : 0, n = c_end - lo;
+            if (n <= 0) continue;
+            const int pieces = (n + per - 1) / per;
+            const int tile = (ti << 16) | tj;
+            if (pieces == 1) {
+                items.push_back({tile, lo, c_end, -1});
+                continue;
+            }
+            red.push_back({tile, next_slab, pieces, 0});
+            for (int s = 0; s < pieces; ++s) {
+                const int a = lo + (int)((long)n * s / pieces), b = lo + (int)((long)n * (s + 1) / pieces);
+                items.push_back({tile, a, b, next_slab++});
+            }
+        }
+    // longest items first (they all start in the first round; the order only matters beyond 256 items)
+    std::stable_sort(items.begin(), items.end(),
+                     [](const G3Item& x, const G3Item& y) { return (x.c_hi - x.c_lo) > (y.c_hi - y.c_lo); });
+}
+
+// ---- C-ABI face (tests and micro-benchmarks; the hot path calls qt_gemm3_launch from cholesky.hip) ----
+// C (-)= A^T B with A [k][lda], B [k][ldb] fp32, k a multiple of 128.  kind 0: every tile whole (C -= A^T B);
+// kind 1: split along k into slabs (C = A^T B), as the inverse's block-row product.  Synchronous table upload.
+static size_t g3_test_layout(int M, int N, int k, int64_t& ldp, size_t& planes_bytes, size_t& slabs_bytes) {
+    ldp = (int64_t)qt_align_up((size_t)std::max(M, N), 256);
+    planes_bytes = (size_t)3 * k * ldp * 2;
+    slabs_bytes = (size_t)2 * NUM_CU * BT * BT * 4;
+    return 2 * planes_bytes + slabs_bytes + (size_t)(1 << 20) + 1024;
+}
+
+extern "C" size_t qt_gemm3_tn_f32_workspace_bytes(int M, int N, int k) {
+    if (M <= 0 || N <= 0 || k <= 0) return 0;
+    int64_t ldp;
+    size_t pb, sb;
+    return g3_test_layout(M, N, k, ldp, pb, sb);
+}
+
+extern "C" int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
+                               int N, int k, int kind, void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(A && B && C && M > 0 && N > 0 && k > 0 && k % CH_ROWS == 0, "qt_gemm3_tn_f32: k=%d must be a positive multiple of 128", k);
+    QT_CHECK_ARG(M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "qt_gemm3_tn_f32: M, N, lda, ldb must be multiples of 4");
+    int64_t ldp;
+    size_t pb, sb;
+    const size_t need = g3_test_layout(M, N, k, ldp, pb, sb);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_gemm3_tn_f32: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    char* ws = (char*)qt_align_up((size_t)workspace, 256);
+    unsigned short* Apl = (unsigned short*)ws;
+    unsigned short* Bpl = (unsigned short*)(ws + pb);
+    float* slabs = (float*)(ws + 2 * pb);
+    char* tab = ws + 2 * pb + sb;
+    QT_HIP(hipMemsetAsync(ws, 0, 2 * pb, stream));   // columns M..ldp / N..ldp of the planes
+    int rc = qt_split3_launch(A, lda, k, M, Apl, ldp, (int64_t)k * ldp, 0, 0, 0, stream);
+    if (rc) return rc;
+    rc = qt_split3_launch(B, ldb, k, N, Bpl, ldp, (int64_t)k * ldp, 0, 0, 0, stream);
+    if (rc) return rc;
+    const int Tm = (M + BT - 1) / BT, Tn = (N + BT - 1) / BT, nch = k / CH_ROWS;
+    std::vector<G3Item> items;
+    std::vector<G3Red> red;
+    if (kind == 0) {
+        for (int ti = 0; ti < Tm; ++ti)
+            for (int tj = 0; tj < Tn; ++tj) items.push_back({(ti << 16) | tj, 0, nch, -1});
+    } else {
+        // every tile cut into pieces of <= 2 chunks (bounded by the slab area)
+        int next = 0;
+        for (int ti = 0; ti < Tm; ++ti)
+            for (int tj = 0; tj < Tn; ++tj) {
+                const int pieces = std::min((nch + 1) / 2, std::max(1, 2 * NUM_CU / (Tm * Tn)));
+                red.push_back({(ti << 16) | tj, next, pieces, 0});
+                for (int s = 0; s < pieces; ++s)
+                    items.push_back({(ti << 16) | tj, (int)((long)nch * s / pieces), (int)((long)nch * (s + 1) / pieces), next++});
+            }
+        QT_CHECK_ARG((size_t)next * BT * BT * 4 <= sb, "qt_gemm3_tn_f32: too many tiles for the test face");
+    }
+    const size_t ib = items.size() * sizeof(G3Item), rb = red.size() * sizeof(G3Red);
+    QT_CHECK_ARG(qt_align_up(ib, 256) + rb <= (size_t)(1 << 20), "qt_gemm3_tn_f32: table too large for the test face");
+    QT_HIP(hipStreamSynchronize(stream));
+    QT_HIP(hipMemcpy(tab, items.data(), ib, hipMemcpyHostToDevice));
+    if (rb) QT_HIP(hipMemcpy(tab + qt_align_up(ib, 256), red.data(), rb, hipMemcpyHostToDevice));
+    G3Args g;
+    g.Apl = Apl;
+    g.Bpl = Bpl;
+    g.plane_stride = (int64_t)k * ldp;
+    g.ld = ldp;
+    g.rowA0 = g.rowB0 = 0;
+    g.colA0 = g.colB0 = 0;
+    g.colmax = (int)ldp;
+    g.M = M;
+    g.N = N;
+    g.C = C;
+    g.ldc = ldc;
+    g.mode = kind == 0 ? G3_SUB : G3_SET;
+    g.slabs = slabs;
+    g.items = (const G3Item*)tab;
+    g.n_items = (int)items.size();
+    g.red = (const G3Red*)(tab + qt_align_up(ib, 256));
+    g.n_red = (int)red.size();
+    return qt_gemm3_launch(g, stream);
+}

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "common.h"
+#include "ring_pipe.h"
 
 namespace {
 
@@ -64,58 +65,6 @@ struct XtxParams {
     int thr_chk;         // throttle: units between two progress checks (8, 16 or 32)
 };
 
-// LDS-DMA from inline asm: hipcc does not track it, so it inserts no vmcnt drain in front of later
-// ds_reads or barriers.  Every completion is ordered by hand (counted vmcnt + s_barrier below).
-// saddr form: 64-bit scalar base + 32-bit per-lane byte offset; M0 = wave-uniform LDS destination.
-// Both LDS-DMA instructions of one unit (A panel, B panel) in one statement.  M0 is written in the
-// statement that reads it and is not restored: nothing else in this kernel uses M0 (LDS instructions
-// need none on gfx9+), which the build checks by grepping the kernel's ISA for m0 outside these blocks.
-__device__ __forceinline__ void glds16_pair(unsigned voffA, unsigned voffB, const void* sbase, unsigned ldsA,
-                                            unsigned ldsB) {
-    asm volatile(
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %2\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2"
-        :
-        : "v"(voffA), "v"(voffB), "s"(sbase), "s"(ldsA), "s"(ldsB)
-        : "memory");
-}
-__device__ __forceinline__ void glds16_snapshot(unsigned voff, const void* sbase, unsigned lds_dst) {
-    // 1 KiB of progress words -> LDS scratch; sc1: served by L2, never by this CU's L1 copy of the line
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %1 sc1"
-        :
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-
-__device__ __forceinline__ s16x8 tr_load8(const char* lds_addr) {
-    // two transposing reads: tokens +0..3 and +4..7 (rows are 256 B apart -> +1024 B)
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS s16x4*)(lds_addr));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((QT_LDS s16x4*)(lds_addr + 1024));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// one k-step (16 tokens) of a 32x32 output tile; bf16 and fp16 products are both exact in the fp32
-// accumulator and run at the same MFMA rate, so the checkpoint's own dtype is used as it is
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma16(s16x8 a, s16x8 b, f32x16 c) {
-    if constexpr (F16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
 // pointer wraps every wrap_units units, so the footprint every workgroup streams is that window --
 // L2-resident for small windows, Infinity-Cache-resident for medium ones (profiles/r02_xtx_locality.md).
@@ -129,7 +78,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 // THR_CHK units later, when the counted vmcnt has long retired it); a workgroup more than thr_win
 // units ahead of the slowest STARTED, unfinished member sleeps a bounded while (its other waves wait
 // at the phase barrier).  No workgroup ever waits FOR another: no spin, no dependence on residency.
-constexpr int THR_CHK = 32;
 
 template <bool WRAP, bool F16, bool THROTTLE>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {

@@ -63,6 +63,9 @@ SIGNATURES = {
     "qt_col_absmax_accumulate": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t,
                                          c_void_p]),
     "qt_smoothquant_scales": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "qt_gemm3_tn_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "qt_gemm3_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                c_void_p, c_size_t, c_void_p]),
     "qt_sgemm_tn_f32_workspace_bytes": (c_size_t, [c_int, c_int]),
     "qt_sgemm_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                 c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

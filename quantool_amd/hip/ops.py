@@ -418,6 +418,22 @@ def smoothquant_scales(cmin: torch.Tensor, cmax: torch.Tensor, wmax: torch.Tenso
     return s
 
 
+# ---- fp32-accurate TN product on the bf16 MFMA (tests / micro-benchmarks) ---------------------
+def gemm3_tn(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, kind: int = 0):
+    """kind 0: C -= A^T B in place; kind 1: C = A^T B through k-split slabs.  A [k, M], B [k, N] fp32."""
+    lib = load()
+    _req(A, torch.float32, "A", 2)
+    _req(B, torch.float32, "B", 2)
+    _req(C, torch.float32, "C", 2)
+    k, M = A.shape
+    k2, N = B.shape
+    assert k == k2 and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1 and tuple(C.shape) == (M, N)
+    ws = workspace(lib.qt_gemm3_tn_f32_workspace_bytes(M, N, k), A.device, "gemm3")
+    check("qt_gemm3_tn_f32", lib.qt_gemm3_tn_f32(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(),
+                                                 C.stride(0), M, N, k, kind, ws.data_ptr(), ws.numel(), _stream()))
+    return C
+
+
 # ---- fp32 TN GEMM (tests / micro-benchmarks) ------------------------------------------------
 def sgemm_tn(A: torch.Tensor, B: torch.Tensor, Cin: Optional[torch.Tensor] = None, mode: int = 1,
              skip_zero_k: bool = False, allow_split_k: bool = False, out: Optional[torch.Tensor] = None):

@@ -192,8 +192,7 @@ def test_argsort_desc_stable(ops, dev, K):
     np.testing.assert_array_equal(inv.cpu().numpy()[want], np.arange(K, dtype=np.int32))
 
 
-@pytest.mark.parametrize("K", [64, 128, 200, 384, 1024, 2048])
-def test_cholesky_inverse_upper(ops, oracle, dev, K):
+def _check_factor(ops, oracle, dev, K):
     xb = synth_activations(4 * K, K, seed=K + 1)
     H = oracle.hessian_from_gram(oracle.gram_f64(xb), 8)
     Hd, _, _ = oracle.hessian_dead_and_damp(H, 0.01)
@@ -215,6 +214,26 @@ def test_cholesky_inverse_upper(ops, oracle, dev, K):
     # and it must actually factor H^-1: U^T U Hd ~= I
     resid = got.astype(np.float64).T @ got.astype(np.float64) @ Hd.astype(np.float64) - np.eye(K)
     assert np.abs(resid).max() < 5e-3
+    return got, err_gpu, err_lapack
+
+
+@pytest.mark.parametrize("K", [64, 128, 200, 384, 1024, 2048])
+def test_cholesky_inverse_upper(ops, oracle, dev, K):
+    _check_factor(ops, oracle, dev, K)
+
+
+@pytest.mark.parametrize("K", [768, 1000, 2048])
+def test_cholesky_inverse_upper_bf16x3_products(ops, oracle, dev, K, monkeypatch):
+    """The long-k block-row products on the bf16 MFMA (three bf16 planes per operand, csrc/gemm3_tn.hip) are
+    only chosen for large K; QT_CHOL_G3_MIN_CHUNKS=1 makes every step with a product take them (left-looking
+    outer level), at sizes the oracle still factors in seconds.  Same accuracy bar as the f32-MFMA chain."""
+    monkeypatch.setenv("QT_CHOL_G3", "0")
+    base, e0, _ = _check_factor(ops, oracle, dev, K)
+    monkeypatch.setenv("QT_CHOL_G3", "1")
+    monkeypatch.setenv("QT_CHOL_G3_MIN_CHUNKS", "1")
+    got, e1, el = _check_factor(ops, oracle, dev, K)
+    print(f"K={K}: max error / max|U| vs fp64: f32 chain {e0:.2e}, bf16x3 products {e1:.2e}, fp32 LAPACK {el:.2e}")
+    assert not np.array_equal(got, base), "the bf16x3 path was not taken"
 
 
 def test_cholesky_reports_non_pd(ops, dev):
