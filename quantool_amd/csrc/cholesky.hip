@@ -5,22 +5,25 @@
 // built by qt_hessian_prepare):   A = R^T R (R upper)  =>  Hd = (J R^T J)(J R J) = Ut Ut^T with
 // Ut = J R^T J upper, so Hd^-1 = (Ut^-1)^T (Ut^-1) and, by uniqueness of the Cholesky factor,
 //     U = Ut^-1 = J R^-T J = flat-reverse(Y),   Y = R^-T (lower).
-// Cost 2/3 K^3 flops (vs 4/3 K^3) and every block recurrence below is a k-major "TN" product,
-// i.e. one fp32-MFMA kernel (sgemm_tn) serves the whole chain.  Two block sizes: NB = 128 for the
-// latency-bound panel kernels, NBO = 256 for everything that carries the K^3 work, so that work
-// runs as a few dozen large GEMMs (k = 512, hundreds to thousands of 128x128 tiles, no split-K
-// slabs) instead of one M = 128 split-K product per 128 columns:
-//   potrf, RIGHT-looking over NBO-wide outer blocks J, left-looking inside one (all in place in A):
-//     block row j of J :  A[j, j:] -= sum_{p in J, p<j} R[p, j]^T R[p, j:]   (sgemm SUB, k <= 384)
+// Cost 2/3 K^3 flops (vs 4/3 K^3) and every block recurrence below is a k-major "TN" product.  Two block
+// sizes: NB = 128 for the latency-bound panel kernels, NBO / NBI = 256 for everything that carries the K^3.
+//   potrf over NBO-wide outer blocks J, left-looking inside one (all in place in A):
+//     block row j of J :  A[j, j:] -= sum_{p in J, p<j} R[p, j]^T R[p, j:]   (sgemm SUB, k <= NBO - 128)
 //                         R_jj = chol(A_jj), 32x32 inverses                   (potf2_kernel)
 //                         R[j, j+1:] = R_jj^-T A[j, j+1:]                     (trsm_rt_kernel)
-//     after block J    :  A[J1:, J1:] -= R[J, J1:]^T R[J, J1:]                (sgemm SUB, k = 512,
-//                                                                              upper-triangle tiles only)
-//   R^-T by 512-row block rows I (Y lower, so the k range of a tile starts at its first column):
+//     outer level, small K (no product long enough for the bf16 MFMA) -- RIGHT-looking:
+//       after block J  :  A[J1:, J1:] -= R[J, J1:]^T R[J, J1:]                (sgemm SUB, k = NBO, upper tiles only)
+//     outer level, large K -- LEFT-looking, so the K^3/3 runs as long-k block-row products:
+//       before block J :  A[J, J0:] -= R[:J0, J]^T R[:J0, J0:]                (gemm3 SUB, k = J0; sgemm where short)
+//       after block J  :  bf16 plane copies of R[J, J0:]                      (split3_kernel)
+//   R^-T by NBI-row block rows I (Y lower, so the k range of a tile starts at its first column):
 //     inside I         :  Y_II by the 128-row recurrence  T = sum_{p in I, p<i} R[p, i]^T Y[p, I0:i];
-//                         Y[i, I0:i] = -Dinv_i^T T ;  Y[i, i] = Dinv_i^T     (k <= 384)
-//     left of I        :  T_I = sum_{p<I0} R[p, I]^T Y[p, :I0]               (sgemm SET, k = I0)
-//                         Y[I, :I0] = -Y_II T_I = -(Y_II^T)^T T_I             (transpose + sgemm NEG, k = 512)
+//                         Y[i, I0:i] = -Dinv_i^T T ;  Y[i, i] = Dinv_i^T     (k <= NBI - 128)
+//     left of I        :  T_I = sum_{p<I0} R[p, I]^T Y[p, :I0]               (gemm3 SET / sgemm SET, k = I0)
+//                         Y[I, :I0] = -Y_II T_I = -(Y_II^T)^T T_I             (transpose + sgemm NEG, k = NBI)
+//                         bf16 plane copies of Y[I, :I1]                      (split3_kernel, large K only)
+// gemm3 (gemm3_tn.h) = fp32-accurate product on the bf16 MFMA from three bf16 planes per operand; sgemm
+// (sgemm_tn.h) = the f32-MFMA fmaf chain.
 #include <stdlib.h>
 #include <string.h>
 
@@ -65,8 +68,9 @@ static int chol_nbi() {
 // then LEFT-looking at the outer level (block row J gathers  A[J, J:] -= R[:J0, J]^T R[:J0, J:]  in one
 // long-k product: each element of A is read and written once, where the right-looking k = 256 update of
 // the whole trailing matrix is bound by that read-modify-write), and the inverse's T_I product is the same
-// shape.  QT_CHOL_G3=0 disables; QT_CHOL_G3_MIN_CHUNKS = 128-row k-chunks a product needs (default 768 =
-// 3 per CU).  Item tables for every step are built once per (K, block sizes) in pinned host memory and
+// shape.  QT_CHOL_G3=0 disables; QT_CHOL_G3_MIN_CHUNKS = 128-row k-chunks a product needs (default 256 =
+// one per CU; K = 14336 / 8192 / 4096: 24.2 / 9.5 / 3.6 ms at 64...256, 24.6 at 640, 24.9 at 768; off: 34.0 /
+// 10.7 / 3.6).  Item tables for every step are built once per (K, block sizes) in pinned host memory and
 // uploaded with one async copy per call.
 struct G3Step {
     int n_items = 0, n_red = 0;
@@ -84,7 +88,7 @@ static int chol_g3_min_chunks() {   // read per call: tests switch the path on f
     const char* on = getenv("QT_CHOL_G3");
     if (on && atoi(on) == 0) return 0;
     const char* e = getenv("QT_CHOL_G3_MIN_CHUNKS");
-    const int x = e ? atoi(e) : 768;
+    const int x = e ? atoi(e) : 256;
     return x < 1 ? 1 : x;
 }
 

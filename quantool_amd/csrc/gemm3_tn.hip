@@ -342,9 +342,17 @@ void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items,
     items.clear();
     red.clear();
     const long total = g3_row_chunks(Tm, Tn, c_end, tri);
-    const int budget = std::max(1, NUM_CU - Tm * Tn);   // items <= total / per + tiles <= 256
-    int per = (int)((total + budget - 1) / budget);
-    per = std::max(per, 2);
+    // smallest piece length (in chunks, >= 2) with which all pieces fit one round of the 256 CUs
+    auto count_items = [&](int per) {
+        long n_items = 0;
+        for (int tj = 0; tj < Tn; ++tj) {
+            const int n = c_end - (tri ? 2 * tj : 0);
+            if (n > 0) n_items += (long)Tm * ((n + per - 1) / per);
+        }
+        return n_items;
+    };
+    int per = std::max(2, (int)((total + NUM_CU - 1) / NUM_CU));
+    while (count_items(per) > NUM_CU) ++per;
     int next_slab = 0;
     for (int ti = 0; ti < Tm; ++ti)
         for (int tj = 0; tj < Tn; ++tj) {
