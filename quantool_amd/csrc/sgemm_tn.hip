@@ -9,22 +9,27 @@
 namespace {
 
 constexpr int BK = 16;
-constexpr int NT = 256;
 
 // amdgpu_waves_per_eu(2): the MODE_SUB variants hold a C tile next to the accumulators; capping the
 // register budget at two waves per SIMD makes hipcc park the excess in AGPRs instead of taking all
 // 512 registers (one wave per SIMD leaves the C read / write phases of a workgroup uncovered).
-template <int BM, int BN, int MODE, bool CHAIN = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sgemm_tn_kernel(SgemmArgs p) {  // p is modified per z-slice
-    constexpr int WM = BM / 64, WN = BN / 64;  // 32x32 sub-tiles per wave in m / n
+// NWAVE = 8 (MODE_SUB, 128x128): the same tile on 8 waves (4 x 2, 32x64 outputs each), so a wave holds
+// 32 + 32 accumulator / C registers instead of 64 + 64 and FOUR waves fit a SIMD (two workgroups per CU):
+// the f32 MFMA pipe measured 61 % busy at two waves per SIMD on the sweep's k = 512 updates (PMC,
+// profiles/r02_gemm_pmc.txt).  Per output element the k order is unchanged (bit-identical results).
+template <int BM, int BN, int MODE, bool CHAIN = false, int NWAVE = 4>
+__global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAVE == 8 ? 4 : 2))) void sgemm_tn_kernel(SgemmArgs p) {  // p is modified per z-slice
+    constexpr int NT = 64 * NWAVE;
+    constexpr int WGM = NWAVE == 8 ? 4 : 2, WGN = 2;          // wave grid
+    constexpr int WM = BM / (32 * WGM), WN = BN / (32 * WGN);  // 32x32 sub-tiles per wave in m / n
     constexpr int A4 = BK * BM / 4 / NT;       // float4 loads per thread for A
     constexpr int B4 = BK * BN / 4 / NT;
-    static_assert(A4 >= 1 && B4 >= 1, "tile too small for 256 threads");
+    static_assert(A4 >= 1 && B4 >= 1, "tile too small for the workgroup");
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int wave_m = wave >> 1, wave_n = wave & 1;   // WGN == 2
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (p.upper_only && m0 >= n0 + BN) return;   // every row of this tile lies below every column: not wanted
     const bool tile_inside = p.fast_interior && m0 + BM <= p.M && n0 + BN <= p.N;   // wave-uniform
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wave_m * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
+                    const int row = m0 + wave_m * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int col = n0 + wave_n * (BN / WGN) + j * 32 + l31;
                     cpre[i][j][r] = (tile_inside || (row < p.M && col < p.N)) ? p.Cin[(size_t)row * p.ldcin + col] : 0.0f;
                 }
     }
@@ -149,9 +154,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
             for (int kk = 0; kk < BK / 2; ++kk) {
                 float a[WM], b[WN];
 #pragma unroll
-                for (int i = 0; i < WM; ++i) a[i] = As[buf][2 * kk + h][wave_m * (BM / 2) + i * 32 + l31];
+                for (int i = 0; i < WM; ++i) a[i] = As[buf][2 * kk + h][wave_m * (BM / WGM) + i * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) b[j] = Bs[buf][2 * kk + h][wave_n * (BN / 2) + j * 32 + l31];
+                for (int j = 0; j < WN; ++j) b[j] = Bs[buf][2 * kk + h][wave_n * (BN / WGN) + j * 32 + l31];
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -184,8 +189,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void sg
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wave_m * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = n0 + wave_n * (BN / 2) + j * 32 + l31;
+                const int row = m0 + wave_m * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = n0 + wave_n * (BN / WGN) + j * 32 + l31;
                 if (tile_inside || (row < p.M && col < p.N)) {
                     float v = acc[i][j][r];
                     if (MODE == SG_MODE_SUB) v = cpre[i][j][r] - v;
@@ -238,18 +243,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int BM, int BN>
 int launch(const SgemmArgs& a, hipStream_t stream, int splits = 1) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
+    // 128x128 MODE_SUB tiles on 8 waves (four waves per SIMD) unless QT_SGEMM_SUB_WAVES=4
+    static const bool sub8 = [] {
+        const char* e = getenv("QT_SGEMM_SUB_WAVES");
+        return !(e && atoi(e) == 4);
+    }();
     switch (a.mode) {
         case SG_MODE_SUB:
+            if constexpr (BM == 128 && BN == 128) {
+                if (sub8) {
+                    if (a.chain_len > 0)
+                        hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB, true, 8>), grid, dim3(512), 0, stream, a);
+                    else
+                        hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB, false, 8>), grid, dim3(512), 0, stream, a);
+                    break;
+                }
+            }
             if (a.chain_len > 0)
-                hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB, true>), grid, dim3(NT), 0, stream, a);
+                hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB, true>), grid, dim3(256), 0, stream, a);
             else
-                hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB>), grid, dim3(NT), 0, stream, a);
+                hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SUB>), grid, dim3(256), 0, stream, a);
             break;
         case SG_MODE_SET:
-            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SET>), grid, dim3(NT), 0, stream, a);
+            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_SET>), grid, dim3(256), 0, stream, a);
             break;
         default:
-            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_NEG>), grid, dim3(NT), 0, stream, a);
+            hipLaunchKernelGGL((sgemm_tn_kernel<BM, BN, SG_MODE_NEG>), grid, dim3(256), 0, stream, a);
             break;
     }
     QT_LAUNCH_CHECK();
