@@ -39,27 +39,16 @@ namespace {
 
 constexpr int NB = 128;
 constexpr int NBO_MAX = 1024; // workspace is sized for the widest outer block
-// outer block of the K^3 work (a multiple of 128; QT_CHOL_NBO for A/B runs; measured at K = 14336 / 4096:
-// 128: 40.5 / 4.30 ms, 256: 35.3 / 4.04, 512: 36.4 / 4.05, 1024: 38.5 / 4.40)
-static int chol_nbo() {
-    static const int v = [] {
-        const char* e = getenv("QT_CHOL_NBO");
-        int x = e ? atoi(e) : 256;
-        x = x / 128 * 128;
-        return x < 128 ? 128 : (x > NBO_MAX ? NBO_MAX : x);
-    }();
-    return v;
-}
-// block rows of the inverse phase: its big product has M = this many rows, so wider rows mean fewer,
-// squarer GEMMs (QT_CHOL_NBI for A/B runs)
-static int chol_nbi() {
-    static const int v = [] {
-        const char* e = getenv("QT_CHOL_NBI");
-        int x = e ? atoi(e) : 256;
-        x = x / 128 * 128;
-        return x < 128 ? 128 : (x > NBO_MAX ? NBO_MAX : x);
-    }();
-    return v;
+// Outer block of the factorisation / block-row height of the inverse (multiples of 128).  QT_CHOL_NBO /
+// QT_CHOL_NBI force them (A/B runs); otherwise 256 on the f32 chain (measured at K = 14336 / 4096: 128: 40.5 /
+// 4.30 ms, 256: 35.3 / 4.04, 512: 36.4 / 4.05, 1024: 38.5 / 4.40) and 512 where the bf16x3 products are in
+// use -- two tile rows per product halve the k-split and the slab traffic (K = 14336 / 8192: 23.7 / 9.6 ms at
+// 256 / 256, 23.0 / 9.2 at 512 / 256, 22.8 / 8.9 at 512 / 512; bench 84.5 -> 82.9 ms/step).
+static int chol_block_env(const char* name) {
+    const char* e = getenv(name);
+    if (!e) return 0;
+    int x = atoi(e) / 128 * 128;
+    return x < 128 ? 128 : (x > NBO_MAX ? NBO_MAX : x);
 }
 // ---- bf16x3 block-row products (gemm3_tn.h) ---------------------------------------------------------
 // Where a block-row product of the chain has enough k-chunks to fill the chip with xtx-class items, it
@@ -104,7 +93,7 @@ static const CholG3Plan* chol_g3_plan(int K, int NBO, int NBI) {
     std::vector<char> bytes;
     auto add = [&](int Tm, int Tn, int c_end, int tri) {
         G3Step st;
-        if (min_chunks <= 0 || K % 8 != 0 || g3_row_chunks(Tm, Tn, c_end, tri) < min_chunks) return st;
+        if (min_chunks <= 0 || K % 8 != 0 || g3_row_chunks(Tm, Tn, c_end, tri) * G3_CHUNK_ROWS < (long)min_chunks * 128) return st;
         std::vector<G3Item> items;
         std::vector<G3Red> red;
         g3_plan_row(Tm, Tn, c_end, tri, items, red);
@@ -122,11 +111,11 @@ static const CholG3Plan* chol_g3_plan(int K, int NBO, int NBI) {
     };
     for (int J0 = 0; J0 < K; J0 += NBO) {
         const int J1 = (K - J0 < NBO) ? K : J0 + NBO;
-        pl->fac.push_back(J0 == 0 ? G3Step() : add((J1 - J0 + 255) / 256, (K - J0 + 255) / 256, J0 / 128, 0));
+        pl->fac.push_back(J0 == 0 ? G3Step() : add((J1 - J0 + 255) / 256, (K - J0 + 255) / 256, J0 / G3_CHUNK_ROWS, 0));
     }
     for (int I0 = 0; I0 < K; I0 += NBI) {
         const int I1 = (K - I0 < NBI) ? K : I0 + NBI;
-        pl->inv.push_back(I0 == 0 ? G3Step() : add((I1 - I0 + 255) / 256, (I0 + 255) / 256, I0 / 128, 1));
+        pl->inv.push_back(I0 == 0 ? G3Step() : add((I1 - I0 + 255) / 256, (I0 + 255) / 256, I0 / G3_CHUNK_ROWS, 1));
     }
     if (pl->any) {
         pl->blob_bytes = qt_align_up(bytes.size(), 256);
@@ -149,6 +138,18 @@ static const CholG3Plan* chol_g3_plan(int K, int NBO, int NBI) {
 static size_t chol_g3_ws_bytes(const CholG3Plan* pl, int K) {
     if (!pl->any) return 0;
     return 2 * qt_align_up((size_t)3 * K * K * 2, 256) + (size_t)pl->max_slabs * 256 * 256 * 4 + pl->blob_bytes + 256;
+}
+
+// block sizes and item tables of one call
+static const CholG3Plan* chol_blocks(int K, int& NBO, int& NBI) {
+    const int eo = chol_block_env("QT_CHOL_NBO"), ei = chol_block_env("QT_CHOL_NBI");
+    NBO = eo ? eo : 512;
+    NBI = ei ? ei : 512;
+    const CholG3Plan* pl = chol_g3_plan(K, NBO, NBI);
+    if (pl->any) return pl;
+    NBO = eo ? eo : 256;
+    NBI = ei ? ei : 256;
+    return chol_g3_plan(K, NBO, NBI);
 }
 
 constexpr int LDP = NB + 1;  // padded LDS leading dimension
@@ -518,8 +519,9 @@ extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
     // T panel [128, K] + T_I panel [512, K] + X_II [512, 512] + Rd, Dinv [nb][128*128] each + split-K slabs
     // (a split product writes splits * M * N floats with splits <= 2048 workgroups / tiles: <= 2048 * 128 * 128)
     const size_t split = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
+    int nbo_, nbi_;
     return (size_t)NB * K * 4 + (size_t)NBO_MAX * K * 4 + (size_t)NBO_MAX * NBO_MAX * 4 +
-           nb * (NB * NB + RD_STRIDE) * 4 + split + 256 + chol_g3_ws_bytes(chol_g3_plan(K, chol_nbo(), chol_nbi()), K);
+           nb * (NB * NB + RD_STRIDE) * 4 + split + 256 + chol_g3_ws_bytes(chol_blocks(K, nbo_, nbi_), K);
 }
 
 extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
@@ -535,15 +537,14 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
     float* T = (float*)ws;
     float* TI = T + (size_t)NB * K;
-    const int NBO = chol_nbo();
+    int NBO, NBI;
+    const CholG3Plan* g3 = chol_blocks(K, NBO, NBI);
     float* XT = TI + (size_t)NBO_MAX * K;
     float* Rd = XT + (size_t)NBO_MAX * NBO_MAX;
     float* Dinv = Rd + (size_t)nblk * RD_STRIDE;
     float* split_ws = Dinv + (size_t)nblk * NB * NB;
     const size_t split_ws_bytes = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
-    const int NBI = chol_nbi();
     // bf16x3 products: plane copies of R and Y, slabs, item tables (only when some step uses them)
-    const CholG3Plan* g3 = chol_g3_plan(K, NBO, NBI);
     unsigned short *Rpl = nullptr, *Ypl = nullptr;
     float* g3_slabs = nullptr;
     char* g3_tab = nullptr;

@@ -13,12 +13,14 @@
 
 #include "common.h"
 
-// One workgroup = one item: a 256x256 output tile over k rows [128*c_lo, 128*c_hi) of the planes.
+constexpr int G3_CHUNK_ROWS = 64;   // granularity of an item's k range
+
+// One workgroup = one item: a 256x256 output tile over k rows [64*c_lo, 64*c_hi) of the planes (>= 2 chunks).
 struct G3Item {
     int tile;   // (ti << 16) | tj : output rows 256*ti.., columns 256*tj..
-    int c_lo;   // k range in chunks of 128 rows, relative to row0 of the call
+    int c_lo;   // k range in chunks of G3_CHUNK_ROWS rows, relative to row0 of the call
     int c_hi;
-    int slab;   // < 0: the item covers the tile's whole k range and applies it to C itself (C -= acc);
+    int slab;   // < 0: the item covers the tile's whole k range and applies it to C itself (C -= acc / C = acc);
                 // >= 0: partial product -> slab[slab] (256x256 fp32), reduced in table order afterwards
 };
 // One output tile assembled from `count` consecutive slabs starting at `first`.
@@ -59,8 +61,9 @@ int qt_gemm3_launch(const G3Args& a, hipStream_t stream);
 int qt_split3_launch(const float* src, int64_t ld_src, int rows, int cols, unsigned short* planes, int64_t ld_pl,
                      int64_t plane_stride, int mask_upper, int row_g0, int col_g0, hipStream_t stream);
 
-// Host-side item table of a block-row product: Tm x Tn tiles over k chunks [lo, c_end), lo = 0, or with
-// tri != 0 lo = 2 * tj (B is lower-triangular in 256-blocks: B[k][n] == 0 for k < 256 * tj); split along k
-// into <= 256 items of near-equal length (one round of the 256 CUs), longest first.
+// Host-side item table of a block-row product: Tm x Tn tiles over k chunks [lo, c_end) (chunks of
+// G3_CHUNK_ROWS rows), lo = 0, or with tri != 0 lo = first chunk of row 256 * tj (B is lower-triangular in
+// 256-blocks: B[k][n] == 0 for k < 256 * tj); split along k into <= 256 items of near-equal length (one round
+// of the 256 CUs), longest first.
 long g3_row_chunks(int Tm, int Tn, int c_end, int tri);
 void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items, std::vector<G3Red>& red);

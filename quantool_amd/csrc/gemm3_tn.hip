@@ -20,8 +20,9 @@ constexpr int UNIT_BYTES = UT * 2 * BT * 2;
 constexpr int RING = 8;
 constexpr int NTHREADS = 512;
 constexpr int NUM_CU = 256;
-constexpr int CH_ROWS = 128;                    // k rows per chunk
-constexpr int CH_UNITS = 6 * (CH_ROWS / UT);    // 48 units: 6 plane products x 8 units
+constexpr int CH_ROWS = G3_CHUNK_ROWS;          // k rows per chunk (64)
+constexpr int CH_UNITS = 6 * (CH_ROWS / UT);    // 24 units: 6 plane products x 4 units
+static_assert(CH_ROWS / UT == 4, "the phase code below recomputes the source pointers every 4 units");
 // plane (0 = hi, 1 = mid, 2 = lo) of the A / B operand in product pr, two bits each, smallest product first:
 //   pr:  0      1      2       3       4       5
 //   A :  lo     hi     mid     mid     hi      hi
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
     const int c_hi = __builtin_amdgcn_readfirstlane(itp->c_hi);
     const int slab_idx = __builtin_amdgcn_readfirstlane(itp->slab);
     const int ti = it_tile >> 16, tj = it_tile & 0xFFFF;
-    const int nu = (c_hi - c_lo) * CH_UNITS;   // a multiple of 48
+    const int nu = (c_hi - c_lo) * CH_UNITS;   // a multiple of 24 (items are >= 2 chunks: nu >= 48)
 
     // staging geometry: as xtx_kernel (wave w fills k rows 4*(w&3)..+3 of column group w>>2; XOR swizzle of
     // the 16-B chunk index on the SOURCE address)
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
     // unit i of the item -> (k chunk, plane product, 16-row slice): scalar source pointers of both panels
     const int64_t ustride = (int64_t)UT * p.ld2;
     auto unit_src = [&](int i, const char*& a, const char*& b) {
-        const int g = i >> 3, j = i & 7;
+        const int g = i >> 2, j = i & 3;
         const int c = g / 6, pr = g - 6 * c;
         const int64_t plA = (PA_BITS >> (2 * pr)) & 3u, plB = (PB_BITS >> (2 * pr)) & 3u;
         const int64_t row = (int64_t)(c_lo + c) * CH_ROWS + j * UT;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
         glds16_pair2(voffA, voffB, a, b, d, d + 8192);
     };
     // steady state: running pointers; a body of 8 phases issues units u+6 .. u+13, the plane pair changes
-    // at unit u+8 (phase slot 2), where the pointers are recomputed
+    // at units u+8 and u+12 (phase slots 2 and 6), where the pointers are recomputed
     const char *runA = nullptr, *runB = nullptr;
 
     // fragment read geometry: as xtx_kernel
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) fb[ni] = tr_load8(base + boff[ni]);
         if (STEADY) {
-            if (S == 2) unit_src(u + LEAD, runA, runB);
+            if (S == 2 || S == 6) unit_src(u + LEAD, runA, runB);
             const unsigned d = dst_wave + (unsigned)ISLOT * UNIT_BYTES;
             glds16_pair2(voffA, voffB, runA, runB, d, d + 8192);
             runA += ustride;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
 
     if (nu > 0) {
 #pragma unroll
-        for (int i = 0; i < LEAD; ++i) issue(i, i);   // nu >= 48 > LEAD
+        for (int i = 0; i < LEAD; ++i) issue(i, i);   // nu >= 24 > LEAD
         wait_vmcnt<2 * (LEAD - 1)>();
         __builtin_amdgcn_s_barrier();
         if (group_b) __builtin_amdgcn_s_barrier();   // stagger: group B runs one interval behind
@@ -332,13 +333,17 @@ int qt_split3_launch(const float* src, int64_t ld_src, int rows, int cols, unsig
     return QT_OK;
 }
 
+// k ranges are counted in chunks of G3_CHUNK_ROWS rows; a 256-column tile column tj of a lower-triangular B
+// starts at chunk tj * (256 / G3_CHUNK_ROWS)
 long g3_row_chunks(int Tm, int Tn, int c_end, int tri) {
+    constexpr int TRI_STEP = 256 / G3_CHUNK_ROWS;
     long total = 0;
-    for (int tj = 0; tj < Tn; ++tj) total += (long)Tm * std::max(0, c_end - (tri ? 2 * tj : 0));
+    for (int tj = 0; tj < Tn; ++tj) total += (long)Tm * std::max(0, c_end - (tri ? TRI_STEP * tj : 0));
     return total;
 }
 
 void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items, std::vector<G3Red>& red) {
+    constexpr int TRI_STEP = 256 / G3_CHUNK_ROWS;
     items.clear();
     red.clear();
     const long total = g3_row_chunks(Tm, Tn, c_end, tri);
@@ -346,17 +351,17 @@ void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items,
     auto count_items = [&](int per) {
         long n_items = 0;
         for (int tj = 0; tj < Tn; ++tj) {
-            const int n = c_end - (tri ? 2 * tj : 0);
+            const int n = c_end - (tri ? TRI_STEP * tj : 0);
             if (n > 0) n_items += (long)Tm * ((n + per - 1) / per);
         }
         return n_items;
     };
     int per = std::max(2, (int)((total + NUM_CU - 1) / NUM_CU));
-    while (count_items(per) > NUM_CU) ++per;
+    while (count_items(per) > NUM_CU && per < c_end) ++per;   // more tiles than CUs: one item per tile
     int next_slab = 0;
     for (int ti = 0; ti < Tm; ++ti)
         for (int tj = 0; tj < Tn; ++tj) {
-            const int lo = tri ? 2 * tj : 0, n = c_end - lo;
+            const int lo = tri ? TRI_STEP * tj : 0, n = c_end - lo;
             if (n <= 0) continue;
             const int pieces = (n + per - 1) / per;
             const int tile = (ti << 16) | tj;
@@ -395,7 +400,7 @@ extern "C" size_t qt_gemm3_tn_f32_workspace_bytes(int M, int N, int k) {
 extern "C" int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                                int N, int k, int kind, void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    QT_CHECK_ARG(A && B && C && M > 0 && N > 0 && k > 0 && k % CH_ROWS == 0, "qt_gemm3_tn_f32: k=%d must be a positive multiple of 128", k);
+    QT_CHECK_ARG(A && B && C && M > 0 && N > 0 && k > 0 && k % 128 == 0, "qt_gemm3_tn_f32: k=%d must be a positive multiple of 128", k);
     QT_CHECK_ARG(M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "qt_gemm3_tn_f32: M, N, lda, ldb must be multiples of 4");
     int64_t ldp;
     size_t pb, sb;
@@ -425,7 +430,7 @@ extern "C" int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int6
         int next = 0;
         for (int ti = 0; ti < Tm; ++ti)
             for (int tj = 0; tj < Tn; ++tj) {
-                const int pieces = std::min((nch + 1) / 2, std::max(1, 2 * NUM_CU / (Tm * Tn)));
+                const int pieces = std::min(nch / 2, std::max(1, 2 * NUM_CU / (Tm * Tn)));   // >= 2 chunks each
                 red.push_back({(ti << 16) | tj, next, pieces, 0});
                 for (int s = 0; s < pieces; ++s)
                     items.push_back({(ti << 16) | tj, (int)((long)nch * s / pieces), (int)((long)nch * (s + 1) / pieces), next++});
