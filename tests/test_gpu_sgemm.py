@@ -68,3 +68,30 @@ def test_sgemm_split_k_and_zero_skip(ops, dev):
     full = ops.sgemm_tn(Al, Bl, None, 1)
     skip = ops.sgemm_tn(Al, Bl, None, 1, skip_zero_k=True)
     assert torch.equal(full, skip)
+
+
+def test_sgemm_sub_large_ragged_tiles_match_small_tile_path(ops, dev):
+    """>= 384 tiles of 128x128 select the 128x128 MODE_SUB kernel (8 waves, four per SIMD); fewer select the
+    64x64 kernel.  Per output element both run the same ascending-k fmaf chain and one subtraction, so the
+    ragged 2000 x 3100 x 200 product must equal, bit for bit, the same product assembled from two column
+    halves that each take the small-tile path -- and a few elements are checked against libm's fmaf."""
+    g = torch.Generator(device=dev).manual_seed(11)
+    k, M, N = 200, 2000, 3100
+    A = torch.randn((k, M), generator=g, device=dev)
+    B = torch.randn((k, N), generator=g, device=dev)
+    C = torch.randn((M, N), generator=g, device=dev)
+    big = ops.sgemm_tn(A, B, C, 0)
+    h = N // 2
+    left = ops.sgemm_tn(A, B[:, :h].contiguous(), C[:, :h].contiguous(), 0)
+    right = ops.sgemm_tn(A, B[:, h:].contiguous(), C[:, h:].contiguous(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(big, torch.cat([left, right], 1))
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fmaf.restype = ctypes.c_float
+    libm.fmaf.argtypes = [ctypes.c_float] * 3
+    An, Bn, Cn, out = A.cpu().numpy(), B.cpu().numpy(), C.cpu().numpy(), big.cpu().numpy()
+    for (m, n) in [(0, 0), (1999, 3099), (1920, 3072), (127, 128), (1000, 1555)]:
+        acc = 0.0
+        for kk in range(k):
+            acc = libm.fmaf(float(An[kk, m]), float(Bn[kk, n]), acc)
+        assert np.float32(Cn[m, n]) - np.float32(acc) == out[m, n]
