@@ -62,7 +62,7 @@ struct XtxParams {
     unsigned* progress;  // [rounds][256] progress words of the direct items (zeroed per launch), or null
     int thr_win;         // throttle: units a workgroup may lead the slowest started member by
     int thr_nap;         // throttle: s_sleep argument of one nap (x64 cycles)
-    int thr_chk;         // throttle: units between two progress checks (8, 16 or 32)
+    int thr_chk;         // throttle: units between two progress checks (a power of two, 8..256; 32 by default)
 };
 
 // WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
@@ -73,9 +73,9 @@ struct XtxParams {
 // While they stay within a few thousand tokens of each other, a panel missed by one XCD's L2 is in the
 // 256 MiB Infinity Cache for the other seven; once they drift apart it comes from HBM, and the chip
 // -- power-limited in this kernel -- lowers its clock (profiles/r02_xtx_locality_sweep.txt: 1.31 PF with
-// HBM-served misses, 1.43-1.50 with on-die ones).  Every THR_CHK units wave 0 of a direct item
+// HBM-served misses, 1.43-1.50 with on-die ones).  Every thr_chk (32) units wave 0 of a direct item
 // publishes its unit index and snapshots the round's 256 progress words (one 1 KiB LDS-DMA, read
-// THR_CHK units later, when the counted vmcnt has long retired it); a workgroup more than thr_win
+// thr_chk units later, when the counted vmcnt has long retired it); a workgroup more than thr_win
 // units ahead of the slowest STARTED, unfinished member sleeps a bounded while (its other waves wait
 // at the phase barrier).  No workgroup ever waits FOR another: no spin, no dependence on residency.
 
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
     bool snap_pending = false;
     auto throttle_step = [&](int u) {
         if (snap_pending) {
-            // the snapshot issued THR_CHK units ago: 4 progress words per lane (0 = not started)
+            // the snapshot issued thr_chk units ago: 4 progress words per lane (0 = not started)
             const unsigned* sp = (const unsigned*)(ring + RING * UNIT_BYTES) + lane * 4;
             unsigned m = 0xffffffffu;
 #pragma unroll
