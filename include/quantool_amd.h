@@ -192,6 +192,14 @@ int qt_sgemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, co
                     int64_t ldcin, float* Cout, int64_t ldcout, int M, int N, int kdim, int skip_zero_k,
                     int mode, int allow_split_k, void* workspace, size_t workspace_bytes, qt_stream_t stream);
 
+/* ---- scale * <H, X^T X>_F without storing X^T X (the Gram kernel's epilogue multiplies its tile with H's;
+ * building block of a12's search loss <X^T X, D^T D>; exposed for tests) -----------------------------
+ * X [n_tokens, K] bf16 / fp16 with ldx == K and n_tokens % 64 == 0; H [K, K] fp32, lower triangle read.
+ * *out = (accumulate ? *out : 0) + scale * sum_{i,j} H[i][j] (X^T X)[i][j]; fp64 partial sums in a fixed order. */
+size_t qt_xtx_dot_workspace_bytes(int64_t n_tokens, int K);
+int qt_xtx_dot(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, const float* H, double scale,
+               float* out, int accumulate, void* workspace, size_t workspace_bytes, qt_stream_t stream);
+
 /* ---- fp32-accurate "TN" product on the bf16 MFMA (three bf16 planes per operand, six plane products;
  * building block of a8's K^3 products; exposed for tests) ---------------------------------------
  * A [k][lda], B [k][ldb] fp32, k a multiple of 128, M / N / lda / ldb multiples of 4.

@@ -221,6 +221,102 @@ __global__ __launch_bounds__(64) void awq_pseudo_quant_kernel(const void* __rest
     }
 }
 
+// The common case -- 16-bit weights, group_size 128 -- at 16 bytes per lane: 16 lanes cover one (row, group),
+// a 256-thread block covers 16 of them; min / max / amax are reduced with xor-shuffles inside the 16-lane
+// group (order-independent), every element goes through exactly the operations of awq_pseudo_quant_kernel.
+// The wave-per-group kernel above moves 2 bytes per lane in 128-byte wave accesses (measured 1.1 TB/s over
+// the 20 grid points of a Llama-3-8B layer).
+template <int DIFF>
+__global__ __launch_bounds__(256) void awq_pseudo_quant_g128_kernel(const unsigned short* __restrict__ W, int dtype,
+                                                                    int R, int K, int64_t ldw,
+                                                                    const float* __restrict__ s, int symmetric,
+                                                                    int num_bits, void* __restrict__ out, int64_t ldo) {
+    const int gpr = K >> 7;                                    // groups per row
+    const long grp = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    const bool live = grp < (long)R * gpr;                      // whole 16-lane groups are live or not
+    const long grpc = live ? grp : 0;
+    const int r = (int)(grpc / gpr), g = (int)(grpc - (long)r * gpr);
+    const int k0 = g * 128 + sub * 8;
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    const u16x8 raw = *(const u16x8*)(W + (size_t)r * ldw + k0);
+    const f32x4 s0 = *(const f32x4*)(s + k0), s1 = *(const f32x4*)(s + k0 + 4);
+    float w[8], ws[8], sk[8];
+    float mx = -INFINITY, mn = INFINITY, amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sk[e] = e < 4 ? s0[e] : s1[e - 4];
+        w[e] = qt_h16_to_f32(raw[e], dtype);
+        ws[e] = w[e] * sk[e];
+        mx = fmaxf(mx, ws[e]);
+        mn = fminf(mn, ws[e]);
+        amax = fmaxf(amax, fabsf(ws[e]));
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        mn = fminf(mn, __shfl_xor(mn, off));
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+    }
+    if (!live) return;
+    float res[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float q;
+        if (symmetric) {
+            const float max_int = (float)((1 << (num_bits - 1)) - 1), min_int = -(float)(1 << (num_bits - 1));
+            const float sc = fmaxf(amax, 1e-5f) / max_int;
+            q = fminf(fmaxf(rintf(ws[e] / sc), min_int), max_int) * sc;
+        } else {
+            const float max_int = (float)((1 << num_bits) - 1);
+            const float sc = fmaxf(mx - mn, 1e-5f) / max_int;
+            const float z = fminf(fmaxf(-rintf(mn / sc), 0.0f), max_int);
+            q = (fminf(fmaxf(rintf(ws[e] / sc) + z, 0.0f), max_int) - z) * sc;
+        }
+        res[e] = (DIFF == 0) ? q / sk[e] : w[e] - q / sk[e];
+    }
+    if (DIFF == 2) {
+        float* dst = (float*)out + (size_t)r * K + k0;
+        *(f32x4*)dst = f32x4{res[0], res[1], res[2], res[3]};
+        *(f32x4*)(dst + 4) = f32x4{res[4], res[5], res[6], res[7]};
+    } else {
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (DIFF == 1 || dtype == QT_BF16) o[e] = __builtin_bit_cast(unsigned short, (__bf16)res[e]);
+            else o[e] = __builtin_bit_cast(unsigned short, (_Float16)res[e]);
+        }
+        unsigned short* dst = (unsigned short*)out + (DIFF == 1 ? (size_t)r * K : (size_t)r * ldo) + k0;
+        *(u16x8*)dst = o;
+    }
+}
+
+// DIFF as awq_pseudo_quant_kernel; picks the 16-byte-per-lane kernel when the layout allows it
+template <int DIFF>
+static int launch_pseudo_quant(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int gs,
+                               int symmetric, int num_bits, void* out, int64_t ldo, hipStream_t stream) {
+    const bool fast = gs == 128 && qt_dtype_is16(w_dtype) && (K & 127) == 0 && (ldw & 7) == 0 &&
+                      (((uintptr_t)W | (uintptr_t)out | (uintptr_t)s) & 15) == 0 && (DIFF != 0 || (ldo & 7) == 0);
+    if (fast) {
+        const long lanes = (long)R * (K >> 7) * 16;
+        hipLaunchKernelGGL(awq_pseudo_quant_g128_kernel<DIFF>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream,
+                           (const unsigned short*)W, w_dtype, R, K, ldw, s, symmetric, num_bits, out, ldo);
+        QT_LAUNCH_CHECK();
+        return QT_OK;
+    }
+    const size_t esz = qt_dtype_size(w_dtype);
+    const size_t osz = DIFF == 1 ? 2 : (DIFF == 2 ? 4 : esz);
+    const int64_t opitch = DIFF == 0 ? ldo : K;
+    for (int row0 = 0; row0 < R; row0 += 32768) {   // gridDim.y limit
+        const int rows = (R - row0 < 32768) ? R - row0 : 32768;
+        hipLaunchKernelGGL(awq_pseudo_quant_kernel<DIFF>, dim3(K / gs, rows), dim3(64), 0, stream,
+                           (const void*)((const char*)W + (size_t)row0 * ldw * esz), w_dtype, rows, K, ldw, s, gs,
+                           symmetric, num_bits, (void*)((char*)out + (size_t)row0 * opitch * osz), ldo);
+        QT_LAUNCH_CHECK();
+    }
+    return QT_OK;
+}
+
 // partial[i] = sum_{j <= i} G[i][j] * C[i][j] * (j < i ? 2 : 1)   (both lower triangles valid)
 __global__ __launch_bounds__(256) void sym_dot_rows_kernel(const float* __restrict__ G, const float* __restrict__ C,
                                                            int K, float* __restrict__ partial) {
@@ -452,18 +548,25 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
     char* xws = (char*)partial + qt_align_up((size_t)K * 4, 256);
     const size_t xws_bytes = workspace_bytes - (size_t)(xws - (char*)workspace);
     if (!exact) {
-        hipLaunchKernelGGL(awq_pseudo_quant_kernel<1>, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s,
-                           gs, symmetric, num_bits, D, (int64_t)K);
-        QT_LAUNCH_CHECK();
+        int rcq = launch_pseudo_quant<1>(W, w_dtype, R, K, ldw, s, gs, symmetric, num_bits, D, (int64_t)K, stream);
+        if (rcq) return rcq;
+        // <X^T X, D^T D> straight from the Gram kernel's accumulators (no D^T D in memory, no second pass);
+        // QT_AWQ_FUSED_DOT=0 or an unsuitable layout: materialise D^T D and multiply in a second pass
+        static const bool fused = [] { const char* e = getenv("QT_AWQ_FUSED_DOT"); return !(e && atoi(e) == 0); }();
+        if (fused && qt_xtx_frobenius_workspace_bytes(R, K) <= xws_bytes) {
+            const int rcf = qt_xtx_frobenius(D, QT_BF16, R, K, K, Gfull, (double)weight / ((double)n_tokens * (double)R),
+                                             loss_out, accumulate, xws, xws_bytes, stream);
+            if (rcf == QT_OK) return QT_OK;
+            if (rcf != QT_ERR_UNSUPPORTED) return rcf;
+        }
         QT_HIP(hipMemsetAsync(C, 0, (size_t)K * K * 4, stream));
         const int rc = qt_xtx_accumulate(D, QT_BF16, R, K, K, C, xws, xws_bytes, stream_);
         if (rc) return rc;
     } else {
         // D in fp32 and D^T D on the f32 MFMA: one ascending-k fmaf chain per entry, no bf16 rounding of
         // D.  16x the MFMA time of the fast form: used only to break near-ties of the 20-point search.
-        hipLaunchKernelGGL(awq_pseudo_quant_kernel<2>, dim3(K / gs, R), dim3(64), 0, stream, W, w_dtype, R, K, ldw, s,
-                           gs, symmetric, num_bits, D, (int64_t)K);
-        QT_LAUNCH_CHECK();
+        int rcq = launch_pseudo_quant<2>(W, w_dtype, R, K, ldw, s, gs, symmetric, num_bits, D, (int64_t)K, stream);
+        if (rcq) return rcq;
         SgemmArgs g;
         g.A = (const float*)D; g.lda = K;
         g.B = (const float*)D; g.ldb = K;
@@ -501,15 +604,7 @@ extern "C" int qt_awq_pseudo_quantize(const void* W, int w_dtype, int R, int K, 
         qt_set_error("qt_awq_pseudo_quantize: group_size %d unsupported", gs);
         return QT_ERR_UNSUPPORTED;
     }
-    const size_t esz = qt_dtype_size(w_dtype);
-    for (int row0 = 0; row0 < R; row0 += 32768) {   // gridDim.y limit
-        const int rows = (R - row0 < 32768) ? R - row0 : 32768;
-        hipLaunchKernelGGL(awq_pseudo_quant_kernel<0>, dim3(K / gs, rows), dim3(64), 0, stream,
-                           (const void*)((const char*)W + (size_t)row0 * ldw * esz), w_dtype, rows, K, ldw, s, gs,
-                           symmetric, num_bits, (void*)((char*)out + (size_t)row0 * ldo * esz), ldo);
-        QT_LAUNCH_CHECK();
-    }
-    return QT_OK;
+    return launch_pseudo_quant<0>(W, w_dtype, R, K, ldw, s, gs, symmetric, num_bits, out, ldo, stream);
 }
 
 extern "C" int qt_scale_columns(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* s, int divide,

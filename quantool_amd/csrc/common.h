@@ -52,6 +52,12 @@ void qt_prof_mark(int kernel_id, hipStream_t stream);  // no-op unless qt_profil
 
 static inline size_t qt_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// xtx.hip, internal: *loss_out (+)= scale * <H, X^T X>_F with the product never stored (the Gram kernel's
+// epilogue multiplies its tile with H's).  QT_ERR_UNSUPPORTED when the layout needs the two-pass form.
+size_t qt_xtx_frobenius_workspace_bytes(int64_t n_tokens, int K);
+int qt_xtx_frobenius(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, const float* H, double scale,
+                     float* loss_out, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 // Wave priority of the latency-bound chain kernels (sweep block, panel factor, panel solve): their
 // sparse dependent instruction streams lose issue arbitration to co-resident MFMA-dense waves that run
 // their clusters at s_setprio 1; raised, a chain step runs closer to its stand-alone time while the

@@ -63,6 +63,10 @@ struct XtxParams {
     int thr_win;         // throttle: units a workgroup may lead the slowest started member by
     int thr_nap;         // throttle: s_sleep argument of one nap (x64 cycles)
     int thr_chk;         // throttle: units between two progress checks (a power of two, 8..256; 32 by default)
+    // DOT variant of xtx16_kernel (qt_xtx_frobenius): instead of storing its tile, every item writes
+    // <H tile, its partial tile> (lower triangle, off-diagonal entries twice) to dot_partials[item]
+    const float* H;
+    double* dot_partials;
 };
 
 // WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
@@ -391,7 +395,7 @@ __device__ __forceinline__ f32x4 mfma32(s16x8 a, s16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool F16>
+template <bool F16, bool DOT = false>
 __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
     constexpr int ND = 5;       // doubles resident in LDS
     constexpr int LEAD = 3;     // double d+LEAD is issued in phase d  (LEAD <= ND-2)
@@ -556,6 +560,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
 
     // epilogue: 16x16 tiles, lane = column (B channel), registers = 4 consecutive rows (A channels)
     const int jl = lane & 15, ih = 4 * (lane >> 4);
+    if (DOT) {
+        // <H, X^T X> is linear in the token chunks, so every item -- whole tile or chunk of one -- contributes
+        // <H tile, its accumulators>: no slab, no store of the product.  fp64 partial sums in a fixed order
+        // (registers, lanes by xor-shuffle, waves 0..7), one double per item, summed in item order afterwards.
+        double part = 0.0;
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai)
+#pragma unroll
+            for (int bj = 0; bj < 4; ++bj) {
+                const int gj = tj * BT + wave_n * 64 + bj * 16 + jl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = ti * BT + wave_m * 128 + ai * 16 + ih + r;
+                    if (gi < K && gj <= gi) {
+                        const double v = (double)p.H[(size_t)gi * K + gj] * (double)acc[ai][bj][r];
+                        part += (gj < gi) ? 2.0 * v : v;
+                    }
+                }
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        double* red = (double*)ring;     // the ring is idle: every wave is past its last read
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double t = red[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) t += red[w];
+            p.dot_partials[logical] = t;
+        }
+        return;
+    }
     if (slab_idx < 0) {
 #pragma unroll
         for (int ai = 0; ai < 8; ++ai)
@@ -754,6 +790,8 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
     p.thr_win = 128;
     p.thr_nap = 127;
     p.thr_chk = 32;
+    p.H = nullptr;
+    p.dot_partials = nullptr;
     {
         const char* e = getenv("QT_XTX_ABLATE_WRAP");  // timing-only ablation, see xtx_kernel<true>
         p.wrap_units = e ? atoi(e) : 0;
@@ -851,4 +889,104 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
         return launch(ptp, pt);
     }
     return launch(p, pl);
+}
+
+// ---- internal: loss = scale * <H, X^T X>_F without materialising X^T X (awq.hip) -----------------------------
+// H: [K, K] fp32 with a valid lower triangle.  Every work item of the usual plan (whole tiles and token chunks
+// alike) writes one fp64 partial; sum_partials_kernel adds them in item order.  Needs n_tokens % 64 == 0 and
+// ldx == K (the callers' D matrices); returns QT_ERR_UNSUPPORTED otherwise so the caller takes the two-pass form.
+namespace {
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int n, double scale,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)(red[0] * scale);
+        *out = accumulate ? *out + v : v;
+    }
+}
+}  // namespace
+
+size_t qt_xtx_frobenius_workspace_bytes(int64_t n_tokens, int K) {
+    if (n_tokens <= 0 || K <= 0) return 0;
+    XtxPlan pl = xtx_plan(n_tokens, K);
+    const size_t grid = (size_t)pl.n_direct + (size_t)pl.n_rem * pl.s2;
+    return pl.tab_bytes + qt_align_up(grid * sizeof(double), 256) + 256;
+}
+
+int qt_xtx_frobenius(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, const float* H, double scale,
+                     float* loss_out, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!qt_dtype_is16(x_dtype) || K <= 0 || K % 8 != 0 || ldx != K || n_tokens <= 0 || n_tokens % BKT != 0 ||
+        ((uintptr_t)X & 15) != 0 || (uint64_t)ldx * 2 * UT + (uint64_t)K * 2 >= ((uint64_t)1 << 32))
+        return QT_ERR_UNSUPPORTED;
+    XtxPlan pl = xtx_plan(n_tokens, K);
+    const size_t need = qt_xtx_frobenius_workspace_bytes(n_tokens, K);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_xtx_frobenius: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    char* ws = (char*)qt_align_up((size_t)workspace, 256);
+    int* tile_tab = (int*)ws;
+    double* partials = (double*)(ws + pl.tab_bytes);
+    const int* host_tab = xtx_host_table(K, pl.n_tiles);
+    if (!host_tab) {
+        qt_set_error("qt_xtx_frobenius: could not build the tile table for K=%d", K);
+        return QT_ERR_HIP;
+    }
+    QT_HIP(hipMemcpyAsync(tile_tab, host_tab, (size_t)pl.n_tiles * 4, hipMemcpyHostToDevice, stream));
+    XtxParams p;
+    p.X = X;
+    p.tail = nullptr;
+    p.ldx = ldx;
+    p.K = K;
+    p.n_tt = pl.n_tt;
+    p.has_tail = 0;
+    p.tile_tab = tile_tab;
+    p.n_direct = pl.n_direct;
+    p.n_rem = pl.n_rem;
+    p.s2 = pl.s2;
+    p.slabs = nullptr;
+    p.G = nullptr;
+    {
+        const char* e = getenv("QT_XTX_MAP");
+        p.map_mode = e ? atoi(e) : 0;
+    }
+    p.wrap_units = 0;
+    p.progress = nullptr;
+    p.thr_win = 128;
+    p.thr_nap = 127;
+    p.thr_chk = 32;
+    p.H = H;
+    p.dot_partials = partials;
+    const int grid = pl.n_direct + pl.n_rem * pl.s2;
+    qt_prof_mark(QT_PROF_XTX, stream);
+    if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx16_kernel<true, true>), dim3(grid), dim3(NTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((xtx16_kernel<false, true>), dim3(grid), dim3(NTHREADS), 0, stream, p);
+    qt_prof_mark(QT_PROF_XTX, stream);
+    QT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const double*)partials, grid, scale, loss_out,
+                       accumulate);
+    QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+// C-ABI face of the fused product (tests; awq.hip calls qt_xtx_frobenius directly)
+extern "C" size_t qt_xtx_dot_workspace_bytes(int64_t n_tokens, int K) { return qt_xtx_frobenius_workspace_bytes(n_tokens, K); }
+
+extern "C" int qt_xtx_dot(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, const float* H, double scale,
+                          float* out, int accumulate, void* workspace, size_t workspace_bytes, qt_stream_t stream) {
+    QT_CHECK_ARG(X && H && out, "qt_xtx_dot: null pointer");
+    const int rc = qt_xtx_frobenius(X, x_dtype, n_tokens, K, ldx, H, scale, out, accumulate, workspace, workspace_bytes,
+                                    (hipStream_t)stream);
+    if (rc == QT_ERR_UNSUPPORTED)
+        qt_set_error("qt_xtx_dot: needs 16-bit X, ldx == K, K %% 8 == 0 and n_tokens %% 64 == 0 (got K=%d ldx=%lld n=%lld)", K,
+                     (long long)ldx, (long long)n_tokens);
+    return rc;
 }

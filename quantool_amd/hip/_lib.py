@@ -5,7 +5,7 @@ The product path has no CPU fallback: if the HIP library is missing this module 
 from __future__ import annotations
 
 import ctypes
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent.parent
@@ -63,6 +63,9 @@ SIGNATURES = {
     "qt_col_absmax_accumulate": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t,
                                          c_void_p]),
     "qt_smoothquant_scales": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "qt_xtx_dot_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "qt_xtx_dot": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_double, c_void_p, c_int, c_void_p,
+                           c_size_t, c_void_p]),
     "qt_gemm3_tn_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "qt_gemm3_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                 c_void_p, c_size_t, c_void_p]),

@@ -418,6 +418,23 @@ def smoothquant_scales(cmin: torch.Tensor, cmax: torch.Tensor, wmax: torch.Tenso
     return s
 
 
+# ---- <H, X^T X>_F from the Gram kernel's accumulators (tests; the AWQ loss uses it internally) -------
+def xtx_dot(X: torch.Tensor, H: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None,
+            accumulate: bool = False) -> torch.Tensor:
+    """scale * sum_ij H[i][j] (X^T X)[i][j] with H's lower triangle read; X [n, K] bf16 / fp16 contiguous."""
+    lib = load()
+    code = _act16(X, "X")
+    _req(H, torch.float32, "H", 2)
+    n, K = X.shape
+    assert X.is_contiguous() and H.is_contiguous() and tuple(H.shape) == (K, K)
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=X.device)
+    ws = workspace(lib.qt_xtx_dot_workspace_bytes(n, K), X.device, "xtx_dot")
+    check("qt_xtx_dot", lib.qt_xtx_dot(X.data_ptr(), code, n, K, K, H.data_ptr(), float(scale),
+                                       out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
 # ---- fp32-accurate TN product on the bf16 MFMA (tests / micro-benchmarks) ---------------------
 def gemm3_tn(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, kind: int = 0):
     """kind 0: C -= A^T B in place; kind 1: C = A^T B through k-split slabs.  A [k, M], B [k, N] fp32."""

@@ -340,3 +340,30 @@ def test_pack_and_dequant_exact(ops, oracle, dev, R, K, perm):
     torch.cuda.synchronize()
     want = (Q.astype(np.float32) - zp[:, g_of_col]) * scale[:, g_of_col]
     np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------- a12 building block
+@pytest.mark.parametrize("n,K,dtype", [(256, 256, "bf16"), (1024, 1000, "bf16"), (4096, 2048, "f16"), (640, 4096, "bf16")])
+def test_xtx_dot_is_the_frobenius_product_with_the_gram_matrix(ops, dev, n, K, dtype):
+    """qt_xtx_dot = scale * <H, X^T X>_F straight from the Gram kernel's accumulators (every work item --
+    whole tile or token chunk -- contributes <H tile, its partial tile>): against fp64 on the same 16-bit
+    X and fp32 H.  Floating point: relative error bound 2e-6 (fp32 tile accumulators over <= 4096 tokens,
+    fp64 everywhere after that); accumulate=True adds to the output; run-to-run identical."""
+    g = torch.Generator(device=dev).manual_seed(n + K)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    X = torch.randn((n, K), generator=g, device=dev).to(td)
+    A = torch.randn((K, K), generator=g, device=dev)
+    H = (A + A.t()).contiguous()
+    H_lower_only = torch.tril(H) + torch.triu(torch.full_like(H, float("nan")), 1)   # the upper triangle is never read
+    out = ops.xtx_dot(X, H_lower_only, scale=0.5)
+    out2 = ops.xtx_dot(X, H_lower_only, scale=0.5)
+    torch.cuda.synchronize()
+    Xd = X.double()
+    want = 0.5 * float(((Xd.t() @ Xd) * H.double()).sum())
+    scale_ref = 0.5 * float(((Xd.t() @ Xd).abs() * H.double().abs()).sum())
+    assert abs(float(out.item()) - want) <= 2e-6 * scale_ref
+    assert torch.equal(out, out2)
+    acc = out.clone()
+    ops.xtx_dot(X, H_lower_only, scale=0.5, out=acc, accumulate=True)
+    torch.cuda.synchronize()
+    assert abs(float(acc.item()) - 2 * float(out.item())) <= 1e-6 * abs(float(out.item())) + 1e-30
