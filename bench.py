@@ -304,6 +304,13 @@ def main():
     for _ in range(args.warmup):
         step(_)
     join_streams(dev)
+    if dist is not None:
+        # warm the collective the timed region ends with (RCCL sets up its point-to-point channels on first
+        # use): the same gather on a small state, part of the warm-up like the W untimed steps
+        from quantool_amd.engine.sharding import gather_state_dict
+
+        gather_state_dict({f"warm.{rank}": torch.zeros(1 << 20, dtype=torch.uint8, device=dev)}, dst=0,
+                          device=None if REHEARSE else dev)
     barrier()
 
     lib.qt_profile_enable(1)
