@@ -163,7 +163,7 @@ constexpr int RD_STRIDE = NB * NB + 4 * 32 * 32;  // dense R block + four 32x32 
 
 #define QT_SEL4(kb, v0, v1, v2, v3) ((kb) == 0 ? (v0) : (kb) == 1 ? (v1) : (kb) == 2 ? (v2) : (v3))
 
-// potf2: one workgroup (256 threads), Cholesky (upper, A = R^T R) of an n x n block (n <= 128),
+// potf2: one workgroup (512 threads), Cholesky (upper, A = R^T R) of an n x n block (n <= 128),
 // blocked by 32 inside the workgroup so that only 4 x 32 steps are sequential and everything
 // else is f32 MFMA on LDS-resident tiles:
 //   for kb = 0..3:
@@ -196,7 +196,8 @@ __device__ __forceinline__ void mma32_tn(const float* A, int lda, const float* B
 }
 
 // P and Rout may be the same block (the factorisation runs in place): no __restrict__ on them.
-__global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp, int n,
+constexpr int POTF2_THREADS = 512, POTF2_WAVES = POTF2_THREADS / 64;   // 8 waves: the six trailing tiles of a step in one round
+__global__ __launch_bounds__(POTF2_THREADS) void potf2_kernel(const float* P, int64_t ldp, int n,
                                                     float* Rout, int64_t ldr,
                                                     float* __restrict__ Rd, int32_t* info, int col0, int prio) {
     qt_set_chain_prio(prio);
@@ -212,29 +213,29 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp,
     // memory round trip per element (64 of them were ~40 % of this kernel).  Needs ldp % 4 == 0 (then
     // n % 4 == 0 too: n is 128 or K % 128) and a 16-byte aligned P; odd K takes the scalar loop.
     if ((ldp & 3) == 0 && (n & 3) == 0 && (((uintptr_t)P) & 15) == 0) {
-        f32x4 v[16];
+        constexpr int NV = NB * NB / 4 / POTF2_THREADS;
+        f32x4 v[NV];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int e4 = tid + 256 * r;                 // float4 index in the 128 x 32 grid
+        for (int r = 0; r < NV; ++r) {
+            const int e4 = tid + POTF2_THREADS * r;       // float4 index in the 128 x 32 grid
             const int i = e4 >> 5, j = (e4 & 31) * 4;
             const int ic = i < n ? i : n - 1, jc = j < n ? j : n - 4;
             v[r] = *(const f32x4*)(P + (size_t)ic * ldp + jc);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int e4 = tid + 256 * r;
+        for (int r = 0; r < NV; ++r) {
+            const int e4 = tid + POTF2_THREADS * r;
             const int i = e4 >> 5, j = (e4 & 31) * 4;
+            // only the upper triangle is ever read back: (i) takes R[c][i] from lane i's column (i > c), (ii) and
+            // (iii) touch blocks on or above the diagonal, and what (i) / (iii) compute below it is never stored.
+            // Rows are written whole (float4, conflict-free); the strict lower part just holds the input's values.
+            f32x4 x;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int jj = j + q;
-                if (jj < i) continue;                     // lower triangle: written by its mirror
-                const float x = (i < n && jj < n) ? v[r][q] : (i == jj ? 1.0f : 0.0f);
-                As[i * LDA + jj] = x;
-                if (jj > i) As[jj * LDA + i] = x;
-            }
+            for (int q = 0; q < 4; ++q) x[q] = (i < n && j + q < n) ? v[r][q] : (i == j + q ? 1.0f : 0.0f);
+            *(f32x4*)(As + i * LDA + j) = x;
         }
     } else {
-        for (int e = tid; e < NB * NB; e += 256) {
+        for (int e = tid; e < NB * NB; e += POTF2_THREADS) {
             const int i = e / NB, j = e % NB;
             const int lo = i < j ? i : j, hi = i < j ? j : i;
             float v = (i == j) ? 1.0f : 0.0f;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp,
         __syncthreads();
         if (kb == 3) break;
         // ---- (ii) R[kb, a] = X_kb^T A[kb, a], a > kb: one tile per wave (round robin) ----
-        for (int a = kb + 1 + wave; a < 4; a += 4) {
+        for (int a = kb + 1 + wave; a < 4; a += POTF2_WAVES) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp,
             int t = 0;
             for (int a = kb + 1; a < 4; ++a)
                 for (int a2 = a; a2 < 4; ++a2, ++t) {
-                    if ((t & 3) != wave) continue;
+                    if ((t % POTF2_WAVES) != wave) continue;
                     float* Ct = As + (32 * a) * LDA + 32 * a2;
                     f32x16 acc;
 #pragma unroll
@@ -316,13 +317,26 @@ __global__ __launch_bounds__(256) void potf2_kernel(const float* P, int64_t ldp,
         __syncthreads();
     }
     if (bad != 0 && tid == 0) atomicCAS(info, 0, col0 + bad);
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, jj = e % NB;
-        const float v = (jj >= i) ? As[i * LDA + jj] : 0.0f;
-        if (i < n && jj < n && jj >= i) Rout[(size_t)i * ldr + jj] = v;
-        Rd[e] = v;
+    // R out (upper triangle; float4 groups that cross the diagonal carry zeros below it -- nothing reads the
+    // strict lower part of a factored diagonal block) and the dense copy for trsm / the block inverses
+    const bool vec_out = (ldr & 3) == 0 && (n & 3) == 0 && (((uintptr_t)Rout) & 15) == 0;
+    for (int e4 = tid; e4 < NB * NB / 4; e4 += POTF2_THREADS) {
+        const int i = e4 >> 5, j = (e4 & 31) * 4;
+        f32x4 v = *(const f32x4*)(As + i * LDA + j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (j + q >= i) ? v[q] : 0.0f;
+        *(f32x4*)(Rd + i * NB + j) = v;
+        if (i < n && j + 3 >= i && j < n) {
+            if (vec_out) {
+                *(f32x4*)(Rout + (size_t)i * ldr + j) = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (j + q >= i && j + q < n) Rout[(size_t)i * ldr + j + q] = v[q];
+            }
+        }
     }
-    for (int e = tid; e < 4 * 32 * 32; e += 256) Rd[NB * NB + e] = Xs[e];
+    for (int e4 = tid; e4 < 4 * 32 * 32 / 4; e4 += POTF2_THREADS) *(f32x4*)(Rd + NB * NB + 4 * e4) = *(const f32x4*)(Xs + 4 * e4);
 }
 
 // trsm: Z = R^-T B for a 128 x ncols panel on the f32 MFMA, by BLOCKED forward substitution
@@ -639,7 +653,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
                 int rc = qt_sgemm_tn(g, stream);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), potf2_lds, stream, (const float*)Ajj, (int64_t)K, nbj,
+            hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(POTF2_THREADS), potf2_lds, stream, (const float*)Ajj, (int64_t)K, nbj,
                                Ajj, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0, prio);
             QT_LAUNCH_CHECK();
             const int rest = K - j0 - nbj;
