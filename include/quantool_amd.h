@@ -209,6 +209,10 @@ size_t qt_gemm3_tn_f32_workspace_bytes(int M, int N, int k);
 int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M,
                     int N, int k, int kind, void* workspace, size_t workspace_bytes, qt_stream_t stream);
 
+/* Host-only self-check of the bf16x3 block-row planner (runs without a GPU): 0 if every k chunk of every tile is
+ * covered exactly once and the slab / reduction tables are consistent, else a negative code. */
+int qt_gemm3_plan_check(int Tm, int Tn, int c_end, int tri, int* n_items_out, int* n_slabs_out, int* longest_out);
+
 /* ---- measurement aid (bench.py roofline leg; not part of the reference surface) -------------
  * When enabled, HIP events are recorded on the launch stream immediately around the named
  * kernel; qt_profile_read synchronises them, returns the summed device time and the launch

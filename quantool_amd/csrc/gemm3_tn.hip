@@ -462,3 +462,67 @@ extern "C" int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int6
     g.n_red = (int)red.size();
     return qt_gemm3_launch(g, stream);
 }
+
+// Host-only self-check of the block-row planner (no GPU needed; tests/test_gemm3_plan.py): every k chunk of
+// every tile is covered exactly once, whole-range items are direct, partial ones own distinct consecutive
+// slabs listed once in the reduction table, and one round of CUs holds all items whenever that is possible.
+// Returns 0, or a negative code naming the violated property.
+extern "C" int qt_gemm3_plan_check(int Tm, int Tn, int c_end, int tri, int* n_items_out, int* n_slabs_out,
+                                   int* longest_out) {
+    if (Tm <= 0 || Tn <= 0 || c_end <= 0) return -1;
+    std::vector<G3Item> items;
+    std::vector<G3Red> red;
+    g3_plan_row(Tm, Tn, c_end, tri, items, red);
+    const int step = 256 / G3_CHUNK_ROWS;
+    std::vector<int> cover((size_t)Tm * Tn * c_end, 0);
+    std::vector<int> slab_seen;
+    int longest = 0, n_slabs = 0;
+    for (const G3Item& it : items) {
+        const int ti = it.tile >> 16, tj = it.tile & 0xFFFF;
+        if (ti >= Tm || tj >= Tn || it.c_lo >= it.c_hi || it.c_hi > c_end) return -2;
+        const int lo = tri ? step * tj : 0;
+        if (it.c_lo < lo) return -3;
+        for (int c = it.c_lo; c < it.c_hi; ++c) cover[((size_t)ti * Tn + tj) * c_end + c]++;
+        longest = std::max(longest, it.c_hi - it.c_lo);
+        if (it.slab < 0) {
+            if (it.c_lo != lo || it.c_hi != c_end) return -4;   // a direct item must own its tile's whole range
+        } else {
+            if ((int)slab_seen.size() <= it.slab) slab_seen.resize(it.slab + 1, 0);
+            if (slab_seen[it.slab]++) return -5;
+            n_slabs = std::max(n_slabs, it.slab + 1);
+        }
+    }
+    for (int ti = 0; ti < Tm; ++ti)
+        for (int tj = 0; tj < Tn; ++tj)
+            for (int c = 0; c < c_end; ++c) {
+                const int want = (c >= (tri ? step * tj : 0)) ? 1 : 0;
+                if (cover[((size_t)ti * Tn + tj) * c_end + c] != want) return -6;
+            }
+    std::vector<int> in_red(n_slabs, 0);
+    for (const G3Red& r : red) {
+        if (r.count < 2 || r.first < 0 || r.first + r.count > n_slabs) return -7;
+        for (int q = 0; q < r.count; ++q)
+            if (in_red[r.first + q]++) return -8;
+        // the slabs of a reduction entry belong to its tile, in ascending k order
+        int prev_hi = -1;
+        for (int q = 0; q < r.count; ++q) {
+            bool found = false;
+            for (const G3Item& it : items)
+                if (it.slab == r.first + q) {
+                    if (it.tile != r.tile || (prev_hi >= 0 && it.c_lo != prev_hi)) return -9;
+                    prev_hi = it.c_hi;
+                    found = true;
+                }
+            if (!found) return -10;
+        }
+    }
+    for (int q = 0; q < n_slabs; ++q)
+        if (!in_red[q]) return -11;
+    long tiles = 0;
+    for (int tj = 0; tj < Tn; ++tj) tiles += (c_end > (tri ? step * tj : 0)) ? Tm : 0;
+    if (tiles <= NUM_CU && (long)items.size() > NUM_CU) return -12;
+    if (n_items_out) *n_items_out = (int)items.size();
+    if (n_slabs_out) *n_slabs_out = n_slabs;
+    if (longest_out) *longest_out = longest;
+    return 0;
+}
