@@ -87,8 +87,11 @@ int qt_argsort_desc(const float* values, int K, int32_t* perm, int32_t* inv, qt_
  * Given A = flat-reversed damped Hessian (upper triangle read, destroyed), writes
  * U = chol(Hd^-1, upper) [K,K] row-major (strict lower triangle zero-filled).
  * Uses A = R^T R, U = flat-reverse(R^-T) (DESIGN.md "one factorisation instead of three").
- * info (device int32): 0 ok, else 1-based index of the first non-positive pivot; the host
- * applies upstream's LinAlgError fallback (U = I) when it is non-zero. */
+ * info (device int32): 0 ok, else 1-based index of the first non-positive pivot; upstream's
+ * LinAlgError fallback (U = I) is then applied on the device, with no host synchronisation.
+ * For large K (from about 6 k; K % 8 == 0) the two block-row products that carry the K^3 run as fp32-accurate
+ * three-plane bf16 products and the workspace grows by 12 K^2 bytes for the plane copies of
+ * R and R^-T; QT_CHOL_G3=0 keeps the f32-MFMA chain.  Deterministic either way. */
 size_t qt_cholesky_inverse_upper_workspace_bytes(int K);
 int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
                               size_t workspace_bytes, qt_stream_t stream);
