@@ -236,6 +236,38 @@ def test_cholesky_inverse_upper_bf16x3_products(ops, oracle, dev, K, monkeypatch
     assert not np.array_equal(got, base), "the bf16x3 path was not taken"
 
 
+def test_cholesky_bf16x3_products_wide_dynamic_range(ops, oracle, dev, monkeypatch):
+    """Massive-activation channels (x1000 on 2 % of the channels, x0.01 on another 2 %: diag(H) spans ten
+    decades) through the bf16x3 chain: a bf16 plane keeps 8 significant bits of EVERY element whatever its
+    magnitude, so the factor stays as close to the fp64 factor as the f32-MFMA chain's."""
+    K = 1536
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((4 * K, K)).astype(np.float32)
+    big = rng.choice(K, size=K // 50, replace=False)
+    small = rng.choice(np.setdiff1d(np.arange(K), big), size=K // 50, replace=False)
+    X[:, big] *= 1000.0
+    X[:, small] *= 0.01
+    xb = oracle.f32_to_bf16_bits(X)
+    H = oracle.hessian_from_gram(oracle.gram_f64(xb), 8)
+    Hd, _, _ = oracle.hessian_dead_and_damp(H, 0.01)
+    truth = oracle.cholesky_inverse_upper_f64(Hd)
+    scale = np.abs(truth).max()
+    errs = {}
+    for name, env in (("f32", {"QT_CHOL_G3": "0"}), ("bf16x3", {"QT_CHOL_G3": "1", "QT_CHOL_G3_MIN_CHUNKS": "1"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        A = torch.from_numpy(np.ascontiguousarray(Hd[::-1, ::-1])).to(dev)
+        U, info = ops.cholesky_inverse_upper(A)
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        got = U.cpu().numpy().astype(np.float64)
+        errs[name] = np.abs(got - truth).max() / scale
+        # element-wise too: every entry within 1e-4 of its own magnitude or 1e-6 of the largest one
+        assert np.all(np.abs(got - truth) <= 1e-4 * np.abs(truth) + 1e-6 * scale), name
+    print(f"max error / max|U| vs fp64: f32 chain {errs['f32']:.2e}, bf16x3 products {errs['bf16x3']:.2e}")
+    assert errs["bf16x3"] <= max(4 * errs["f32"], 5e-6)
+
+
 def test_cholesky_reports_non_pd(ops, dev):
     K = 256
     A = torch.eye(K, dtype=torch.float32, device=dev)
