@@ -15,12 +15,13 @@ from quantool_amd.core import QuantizerRegistry
 
 dev = torch.device("cuda:0")
 hidden, inter, layers = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (1024, 2816, 2)))
+n_samples, seq = (int(x) for x in (sys.argv[4:6] if len(sys.argv) > 5 else (16, 128)))   # e.g. 512 384: the bench's calibration set
 g = torch.Generator().manual_seed(0)
-data = [{"input_ids": torch.randint(0, 1000, (128,), generator=g)} for _ in range(16)]
+data = [{"input_ids": torch.randint(0, 1000, (seq,), generator=g)} for _ in range(n_samples)]
 probe = torch.randint(0, 1000, (1, 64), generator=g).to(dev)
 for method, level in (("gptq", "W4A16"), ("awq", "W4A16"), ("smoothquant", "W8A8"), ("awq", "W8A16")):
     cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=8,
-                      num_key_value_heads=8, vocab_size=1000, max_position_embeddings=256, tie_word_embeddings=False)
+                      num_key_value_heads=8, vocab_size=1000, max_position_embeddings=max(256, seq), tie_word_embeddings=False)
     torch.manual_seed(0)
     model = LlamaForCausalLM(cfg).to(torch.bfloat16).to(dev)
     with torch.no_grad():
@@ -29,7 +30,7 @@ for method, level in (("gptq", "W4A16"), ("awq", "W4A16"), ("smoothquant", "W8A8
         q = QuantizerRegistry.create(method, model_id="synthetic/mid-llama")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        q.quantize(model=model, level=level, dataset=data, num_calibration_samples=16, max_seq_length=128,
+        q.quantize(model=model, level=level, dataset=data, num_calibration_samples=n_samples, max_seq_length=seq,
                    oneshot_kwargs={"output_dir": tmp})
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
