@@ -280,6 +280,8 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
         cache.append((args, kwargs))
         raise _StopForward
 
+    ph = _Phases(dev)
+    ph.start()
     h = layers[0].register_forward_pre_hook(grab, with_kwargs=True)
     with torch.no_grad():
         for b in batches:
@@ -290,6 +292,7 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
     h.remove()
     # equal-shape samples share a forward from here on (QT_CALIB_BATCH_TOKENS=0: one sample per forward)
     cache = merge_cache(cache, int(os.environ.get("QT_CALIB_BATCH_TOKENS", "32768")))
+    ph.stop("first-layer inputs")
 
     prefix_of = {id(m): n for n, m in model.named_modules()}
     results: Dict[str, Any] = {}
@@ -349,12 +352,17 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 return fn
 
             hooks = [linears[lead].register_forward_pre_hook(add_hook(lead)) for lead in leaders]
+            ph.start()
             for args, kwargs in cache:
                 h0 = args[0] if args else None
                 cur["samples"] = int(h0.shape[0]) if torch.is_tensor(h0) and h0.dim() >= 3 else 1
                 layer(*args, **kwargs)
             for hk in hooks:
                 hk.remove()
+            for a_ in accs.values():
+                a_.flush()
+            ph.stop("calibration forwards + Gram")
+            ph.start()
             # one stream per input group, largest in_features first (longest chain): see streams.py;
             # under torchrun one stream, so that every rank issues its collectives in the same order
             pool = GroupStreams(dev) if world == 1 else None
@@ -397,14 +405,44 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             if pool is not None:
                 pool.join()
             accs.clear()
+            ph.stop("factorise + sweep + pack")
+            ph.start()
             cache = _advance(layer, cache)
+            ph.stop("propagate")
             logger.info(f"quantized {lname}: {len(linears)} Linears in {len(leaders)} input groups")
+    ph.report()
     model._qt_results = results
     acts = qm.resolved_scheme.input_activations
     model._qt_meta = {"weights": qargs.to_config(), "format": qm.resolved_scheme.format, "ignore": list(qm.ignore),
                       "input_activations": acts.to_config() if acts is not None else None}
     model.save_pretrained = types.MethodType(_save_compressed, model)
     return model
+
+
+class _Phases:
+    """QT_CALIB_TIMING=1: wall time per phase of the driver (device-synchronised; diagnostics only)."""
+
+    def __init__(self, dev):
+        self.on = os.environ.get("QT_CALIB_TIMING", "0") not in ("", "0")
+        self.dev, self.t, self.acc = dev, 0.0, {}
+
+    def start(self):
+        if self.on:
+            import time
+
+            torch.cuda.synchronize(self.dev)
+            self.t = time.perf_counter()
+
+    def stop(self, name):
+        if self.on:
+            import time
+
+            torch.cuda.synchronize(self.dev)
+            self.acc[name] = self.acc.get(name, 0.0) + time.perf_counter() - self.t
+
+    def report(self):
+        if self.on:
+            logger.warning("calibration phases: " + ", ".join(f"{k} {v:.3f} s" for k, v in self.acc.items()))
 
 
 def merge_cache(cache: List[tuple], max_tokens: int) -> List[tuple]:
