@@ -162,6 +162,12 @@ int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw, const flo
                 int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, int exact, float weight,
                 int accumulate, float* loss_out, void* workspace, size_t workspace_bytes, qt_stream_t stream);
 /* index_out[0] = index of the first minimum of values[0..n) (n <= 1024): the grid search's argmin. */
+/* All n_grid fast search losses of one balance Linear at once (scales [n_grid][K] row-major): losses[g]
+ * (+)= weight * loss_g, the same quantity n_grid qt_awq_loss(exact = 0) calls compute, from three launches. */
+size_t qt_awq_losses_workspace_bytes(int R, int K, int n_grid);
+int qt_awq_losses(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* scales, int n_grid,
+                  int group_size, int symmetric, int num_bits, const float* Gfull, int64_t n_tokens, float weight,
+                  int accumulate, float* losses, void* workspace, size_t workspace_bytes, qt_stream_t stream);
 int qt_argmin_f32(const float* values, int n, int32_t* index_out, qt_stream_t stream);
 /* out[R,K] (W's dtype, leading dimension ldo) = pseudo_quant(W * s) / s: the trial weights of one
  * grid point, for mappings whose search loss is measured on a parent module's output (q/k/v under

@@ -230,7 +230,11 @@ template <int DIFF>
 __global__ __launch_bounds__(256) void awq_pseudo_quant_g128_kernel(const unsigned short* __restrict__ W, int dtype,
                                                                     int R, int K, int64_t ldw,
                                                                     const float* __restrict__ s, int symmetric,
-                                                                    int num_bits, void* __restrict__ out, int64_t ldo) {
+                                                                    int num_bits, void* __restrict__ out, int64_t ldo,
+                                                                    int64_t s_stride, int64_t out_stride) {
+    // blockIdx.y: grid point (its scales s + y * s_stride, its output out + y * out_stride elements)
+    s += (size_t)blockIdx.y * (size_t)s_stride;
+    const size_t out_off = (size_t)blockIdx.y * (size_t)out_stride;
     const int gpr = K >> 7;                                    // groups per row
     const long grp = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int sub = threadIdx.x & 15;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void awq_pseudo_quant_g128_kernel(const unsign
         res[e] = (DIFF == 0) ? q / sk[e] : w[e] - q / sk[e];
     }
     if (DIFF == 2) {
-        float* dst = (float*)out + (size_t)r * K + k0;
+        float* dst = (float*)out + out_off + (size_t)r * K + k0;
         *(f32x4*)dst = f32x4{res[0], res[1], res[2], res[3]};
         *(f32x4*)(dst + 4) = f32x4{res[4], res[5], res[6], res[7]};
     } else {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void awq_pseudo_quant_g128_kernel(const unsign
             if (DIFF == 1 || dtype == QT_BF16) o[e] = __builtin_bit_cast(unsigned short, (__bf16)res[e]);
             else o[e] = __builtin_bit_cast(unsigned short, (_Float16)res[e]);
         }
-        unsigned short* dst = (unsigned short*)out + (DIFF == 1 ? (size_t)r * K : (size_t)r * ldo) + k0;
+        unsigned short* dst = (unsigned short*)out + out_off + (DIFF == 1 ? (size_t)r * K : (size_t)r * ldo) + k0;
         *(u16x8*)dst = o;
     }
 }
@@ -300,7 +304,8 @@ static int launch_pseudo_quant(const void* W, int w_dtype, int R, int K, int64_t
     if (fast) {
         const long lanes = (long)R * (K >> 7) * 16;
         hipLaunchKernelGGL(awq_pseudo_quant_g128_kernel<DIFF>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream,
-                           (const unsigned short*)W, w_dtype, R, K, ldw, s, symmetric, num_bits, out, ldo);
+                           (const unsigned short*)W, w_dtype, R, K, ldw, s, symmetric, num_bits, out, ldo, (int64_t)0,
+                           (int64_t)0);
         QT_LAUNCH_CHECK();
         return QT_OK;
     }
@@ -553,9 +558,9 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
         // <X^T X, D^T D> straight from the Gram kernel's accumulators (no D^T D in memory, no second pass);
         // QT_AWQ_FUSED_DOT=0 or an unsuitable layout: materialise D^T D and multiply in a second pass
         static const bool fused = [] { const char* e = getenv("QT_AWQ_FUSED_DOT"); return !(e && atoi(e) == 0); }();
-        if (fused && qt_xtx_frobenius_workspace_bytes(R, K) <= xws_bytes) {
+        if (fused && qt_xtx_frobenius_workspace_bytes(R, K, 1) <= xws_bytes) {
             const int rcf = qt_xtx_frobenius(D, QT_BF16, R, K, K, Gfull, (double)weight / ((double)n_tokens * (double)R),
-                                             loss_out, accumulate, xws, xws_bytes, stream);
+                                             loss_out, accumulate, xws, xws_bytes, stream, 1, 0);
             if (rcf == QT_OK) return QT_OK;
             if (rcf != QT_ERR_UNSUPPORTED) return rcf;
         }
@@ -581,6 +586,57 @@ extern "C" int qt_awq_loss(const void* W, int w_dtype, int R, int K, int64_t ldw
     hipLaunchKernelGGL(partial_sum_f64_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, K,
                        (double)weight / ((double)n_tokens * (double)R), loss_out, accumulate);
     QT_LAUNCH_CHECK();
+    return QT_OK;
+}
+
+// All n_grid fast search losses of one balance Linear in three launches: D for every grid point (one launch,
+// [n_grid][R][K] bf16), one Gram launch over all of them with the Frobenius product against X^T X in its
+// epilogue (n_grid times the work items of a single D^T D: short matrices -- R rows play the tokens -- fill
+// the chip only together), one sum per grid point.  losses[g] (+)= weight * loss_g.  Falls back to n_grid
+// qt_awq_loss calls where the layout does not allow it (group size != 128, R % 64, fp32 weights ...).
+extern "C" size_t qt_awq_losses_workspace_bytes(int R, int K, int n_grid) {
+    if (R <= 0 || K <= 0 || n_grid <= 0) return 0;
+    const size_t batched = qt_align_up((size_t)n_grid * R * K * 2, 256) + qt_xtx_frobenius_workspace_bytes(R, K, n_grid) + 1024;
+    const size_t single = qt_awq_loss_workspace_bytes(R, K);
+    return batched > single ? batched : single;
+}
+
+extern "C" int qt_awq_losses(const void* W, int w_dtype, int R, int K, int64_t ldw, const float* scales, int n_grid,
+                             int group_size, int symmetric, int num_bits, const float* Gfull, int64_t n_tokens,
+                             float weight, int accumulate, float* losses, void* workspace, size_t workspace_bytes,
+                             qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && scales && Gfull && losses && R > 0 && K > 0 && n_tokens > 0 && n_grid > 0 && n_grid <= 65535,
+                 "qt_awq_losses: bad arguments");
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_awq_losses: dtype %d unsupported", w_dtype);
+    const size_t need = qt_awq_losses_workspace_bytes(R, K, n_grid);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_awq_losses: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    const int gs = group_size <= 0 ? K : group_size;
+    static const bool fused = [] { const char* e = getenv("QT_AWQ_FUSED_DOT"); return !(e && atoi(e) == 0); }();
+    const bool fast = fused && gs == 128 && qt_dtype_is16(w_dtype) && (K & 127) == 0 && (ldw & 7) == 0 && R % 64 == 0 &&
+                      (((uintptr_t)W | (uintptr_t)scales) & 15) == 0;
+    if (fast) {
+        char* ws = (char*)qt_align_up((size_t)workspace, 256);
+        unsigned short* D = (unsigned short*)ws;
+        char* xws = ws + qt_align_up((size_t)n_grid * R * K * 2, 256);
+        const size_t xws_bytes = workspace_bytes - (size_t)(xws - (char*)workspace);
+        const long lanes = (long)R * (K >> 7) * 16;
+        hipLaunchKernelGGL(awq_pseudo_quant_g128_kernel<1>, dim3((unsigned)((lanes + 255) / 256), n_grid), dim3(256), 0,
+                           stream, (const unsigned short*)W, w_dtype, R, K, ldw, scales, symmetric, num_bits, (void*)D,
+                           (int64_t)K, (int64_t)K, (int64_t)R * K);
+        QT_LAUNCH_CHECK();
+        const int rc = qt_xtx_frobenius(D, QT_BF16, R, K, K, Gfull, (double)weight / ((double)n_tokens * (double)R), losses,
+                                        accumulate, xws, xws_bytes, stream, n_grid, (int64_t)R * K);
+        if (rc != QT_ERR_UNSUPPORTED) return rc;
+    }
+    for (int g = 0; g < n_grid; ++g) {
+        const int rc = qt_awq_loss(W, w_dtype, R, K, ldw, scales + (size_t)g * K, group_size, symmetric, num_bits, Gfull,
+                                   n_tokens, 0, weight, accumulate, losses + g, workspace, workspace_bytes, stream_);
+        if (rc) return rc;
+    }
     return QT_OK;
 }
 

@@ -54,9 +54,11 @@ static inline size_t qt_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 
 // xtx.hip, internal: *loss_out (+)= scale * <H, X^T X>_F with the product never stored (the Gram kernel's
 // epilogue multiplies its tile with H's).  QT_ERR_UNSUPPORTED when the layout needs the two-pass form.
-size_t qt_xtx_frobenius_workspace_bytes(int64_t n_tokens, int K);
+size_t qt_xtx_frobenius_workspace_bytes(int64_t n_tokens, int K, int n_batch);
+// n_batch problems in one launch: X_b = X + b * x_batch_stride elements (same n_tokens, K, H); loss_out[b]
 int qt_xtx_frobenius(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, const float* H, double scale,
-                     float* loss_out, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                     float* loss_out, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                     int n_batch, int64_t x_batch_stride);
 
 // Wave priority of the latency-bound chain kernels (sweep block, panel factor, panel solve): their
 // sparse dependent instruction streams lose issue arbitration to co-resident MFMA-dense waves that run

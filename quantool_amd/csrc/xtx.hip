@@ -67,6 +67,8 @@ struct XtxParams {
     // <H tile, its partial tile> (lower triangle, off-diagonal entries twice) to dot_partials[item]
     const float* H;
     double* dot_partials;
+    int batch_items;          // DOT: work items per problem (the grid holds n_batch problems back to back) ...
+    int64_t x_batch_bytes;    // ... whose X matrices lie this many bytes apart
 };
 
 // WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
@@ -418,6 +420,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
             logical = b;
         }
     }
+    // DOT: several problems (one X each, same K / n_tokens / H) in one launch; item index inside the problem
+    const int item_global = logical;
+    const char* Xb = (const char*)p.X;
+    if (DOT) {
+        const int prob = logical / p.batch_items;
+        logical -= prob * p.batch_items;
+        Xb += (size_t)prob * (size_t)p.x_batch_bytes;
+    }
     int tile_idx, tt0, cnt, slab_idx = -1;
     if (logical < p.n_direct) {
         tile_idx = logical;
@@ -457,9 +467,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
     const size_t ustride = (size_t)UT * ld2;
     auto dbl_src = [&](int d) -> const char* {
         return d >= d_tail ? (const char*)p.tail + (size_t)(d - d_tail) * 2 * ustride
-                           : (const char*)p.X + ((size_t)tt0 * BKT + (size_t)d * 2 * UT) * ld2;
+                           : Xb + ((size_t)tt0 * BKT + (size_t)d * 2 * UT) * ld2;
     };
-    const char* run_src = (const char*)p.X + (size_t)tt0 * BKT * ld2;
+    const char* run_src = Xb + (size_t)tt0 * BKT * ld2;
     auto issue_at = [&](const char* src, int slot) {
         const unsigned d0 = dst_wave + (unsigned)slot * DBL_BYTES;
         glds16_pair(voffA, voffB, src, d0, d0 + 8192);
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx16_kernel(XtxParams p) {
             double t = red[0];
 #pragma unroll
             for (int w = 1; w < 8; ++w) t += red[w];
-            p.dot_partials[logical] = t;
+            p.dot_partials[item_global] = t;
         }
         return;
     }
@@ -792,6 +802,8 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
     p.thr_chk = 32;
     p.H = nullptr;
     p.dot_partials = nullptr;
+    p.batch_items = 1;
+    p.x_batch_bytes = 0;
     {
         const char* e = getenv("QT_XTX_ABLATE_WRAP");  // timing-only ablation, see xtx_kernel<true>
         p.wrap_units = e ? atoi(e) : 0;
@@ -898,7 +910,9 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
 namespace {
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int n, double scale,
                                                            float* __restrict__ out, int accumulate) {
+    // one block per problem: partials [gridDim.x][n], out [gridDim.x]
     __shared__ double red[256];
+    partials += (size_t)blockIdx.x * n;
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
     red[threadIdx.x] = acc;
@@ -909,25 +923,29 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
     }
     if (threadIdx.x == 0) {
         const float v = (float)(red[0] * scale);
-        *out = accumulate ? *out + v : v;
+        out[blockIdx.x] = accumulate ? out[blockIdx.x] + v : v;
     }
 }
 }  // namespace
 
-size_t qt_xtx_frobenius_workspace_bytes(int64_t n_tokens, int K) {
-    if (n_tokens <= 0 || K <= 0) return 0;
+size_t qt_xtx_frobenius_workspace_bytes(int64_t n_tokens, int K, int n_batch) {
+    if (n_tokens <= 0 || K <= 0 || n_batch <= 0) return 0;
     XtxPlan pl = xtx_plan(n_tokens, K);
-    const size_t grid = (size_t)pl.n_direct + (size_t)pl.n_rem * pl.s2;
+    const size_t grid = ((size_t)pl.n_direct + (size_t)pl.n_rem * pl.s2) * n_batch;
     return pl.tab_bytes + qt_align_up(grid * sizeof(double), 256) + 256;
 }
 
 int qt_xtx_frobenius(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, const float* H, double scale,
-                     float* loss_out, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     float* loss_out, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                     int n_batch, int64_t x_batch_stride) {
     if (!qt_dtype_is16(x_dtype) || K <= 0 || K % 8 != 0 || ldx != K || n_tokens <= 0 || n_tokens % BKT != 0 ||
-        ((uintptr_t)X & 15) != 0 || (uint64_t)ldx * 2 * UT + (uint64_t)K * 2 >= ((uint64_t)1 << 32))
+        ((uintptr_t)X & 15) != 0 || (uint64_t)ldx * 2 * UT + (uint64_t)K * 2 >= ((uint64_t)1 << 32) || n_batch <= 0 ||
+        (n_batch > 1 && (x_batch_stride * 2) % 16 != 0))
         return QT_ERR_UNSUPPORTED;
     XtxPlan pl = xtx_plan(n_tokens, K);
-    const size_t need = qt_xtx_frobenius_workspace_bytes(n_tokens, K);
+    const int items = pl.n_direct + pl.n_rem * pl.s2;
+    if ((int64_t)items * n_batch > (int64_t)1 << 30) return QT_ERR_UNSUPPORTED;
+    const size_t need = qt_xtx_frobenius_workspace_bytes(n_tokens, K, n_batch);
     if (!workspace || workspace_bytes < need) {
         qt_set_error("qt_xtx_frobenius: workspace %zu < required %zu", workspace_bytes, need);
         return QT_ERR_WORKSPACE;
@@ -965,26 +983,28 @@ int qt_xtx_frobenius(const void* X, int x_dtype, int64_t n_tokens, int K, int64_
     p.thr_chk = 32;
     p.H = H;
     p.dot_partials = partials;
-    const int grid = pl.n_direct + pl.n_rem * pl.s2;
+    p.batch_items = items;
+    p.x_batch_bytes = x_batch_stride * 2;
+    const int grid = items * n_batch;
     qt_prof_mark(QT_PROF_XTX, stream);
     if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx16_kernel<true, true>), dim3(grid), dim3(NTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((xtx16_kernel<false, true>), dim3(grid), dim3(NTHREADS), 0, stream, p);
     qt_prof_mark(QT_PROF_XTX, stream);
     QT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const double*)partials, grid, scale, loss_out,
-                       accumulate);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(n_batch), dim3(256), 0, stream, (const double*)partials, items, scale,
+                       loss_out, accumulate);
     QT_LAUNCH_CHECK();
     return QT_OK;
 }
 
 // C-ABI face of the fused product (tests; awq.hip calls qt_xtx_frobenius directly)
-extern "C" size_t qt_xtx_dot_workspace_bytes(int64_t n_tokens, int K) { return qt_xtx_frobenius_workspace_bytes(n_tokens, K); }
+extern "C" size_t qt_xtx_dot_workspace_bytes(int64_t n_tokens, int K) { return qt_xtx_frobenius_workspace_bytes(n_tokens, K, 1); }
 
 extern "C" int qt_xtx_dot(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, const float* H, double scale,
                           float* out, int accumulate, void* workspace, size_t workspace_bytes, qt_stream_t stream) {
     QT_CHECK_ARG(X && H && out, "qt_xtx_dot: null pointer");
     const int rc = qt_xtx_frobenius(X, x_dtype, n_tokens, K, ldx, H, scale, out, accumulate, workspace, workspace_bytes,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, 1, 0);
     if (rc == QT_ERR_UNSUPPORTED)
         qt_set_error("qt_xtx_dot: needs 16-bit X, ldx == K, K %% 8 == 0 and n_tokens %% 64 == 0 (got K=%d ldx=%lld n=%lld)", K,
                      (long long)ldx, (long long)n_tokens);

@@ -88,8 +88,12 @@ def search_losses(weights: Sequence[torch.Tensor], scales: torch.Tensor, G: torc
             ops.awq_loss(w, scales[gi], gs, qargs.symmetric, qargs.num_bits, G, n_tokens, losses[gi:gi + 1],
                          exact=exact, weight=w.shape[0] / n_rows, accumulate=j > 0)
 
-    for gi in range(n_grid):
-        score(gi, False)
+    # fast pass: all grid points of a balance Linear in one Gram launch (its short D matrices -- the Linear's
+    # rows play the tokens -- fill the chip only together)
+    sc = scales.contiguous()
+    for j, w in enumerate(weights):
+        ops.awq_losses(w, sc, gs, qargs.symmetric, qargs.num_bits, G, n_tokens, losses, weight=w.shape[0] / n_rows,
+                       accumulate=j > 0)
     best = ops.argmin_first(losses)
     rtol = NEAR_TIE_RTOL if near_tie_rtol is None else near_tie_rtol
     host = losses.tolist()                                   # one small sync per mapping

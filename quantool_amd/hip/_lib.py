@@ -52,6 +52,9 @@ SIGNATURES = {
     "qt_awq_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "qt_awq_loss": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64,
                             c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "qt_awq_losses_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "qt_awq_losses": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                              c_int64, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "qt_argmin_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "qt_awq_pseudo_quantize": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p,
                                        c_int64, c_void_p]),

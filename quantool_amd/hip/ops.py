@@ -344,6 +344,25 @@ def awq_loss(W: torch.Tensor, s: torch.Tensor, group_size: int, symmetric: bool,
                                          ws.data_ptr(), ws.numel(), _stream()))
 
 
+def awq_losses(W: torch.Tensor, scales: torch.Tensor, group_size: int, symmetric: bool, num_bits: int,
+               Gfull: torch.Tensor, n_tokens: int, out: torch.Tensor, *, weight: float = 1.0,
+               accumulate: bool = False) -> None:
+    """out[g] (device fp32 [n_grid]) = (accumulate ? out[g] : 0) + weight * fast search loss for scales[g]."""
+    lib = load()
+    R, K = _w2d(W)
+    _req(scales, torch.float32, "scales", 2)
+    _req(Gfull, torch.float32, "Gfull", 2)
+    _req(out, torch.float32, "out", 1)
+    n_grid = scales.shape[0]
+    assert scales.shape[1] == K and scales.is_contiguous() and Gfull.shape == (K, K) and Gfull.is_contiguous()
+    assert out.numel() == n_grid and out.is_contiguous()
+    ws = workspace(lib.qt_awq_losses_workspace_bytes(R, K, n_grid), W.device, "awq_losses")
+    check("qt_awq_losses", lib.qt_awq_losses(W.data_ptr(), _dtype_code(W), R, K, W.stride(0), scales.data_ptr(), n_grid,
+                                             group_size, int(bool(symmetric)), num_bits, Gfull.data_ptr(), int(n_tokens),
+                                             float(weight), int(bool(accumulate)), out.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), _stream()))
+
+
 def argmin_first(values: torch.Tensor) -> torch.Tensor:
     """Device int32[1]: index of the first minimum (ties keep the lowest index, as upstream's search loop)."""
     lib = load()

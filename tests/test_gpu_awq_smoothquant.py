@@ -218,3 +218,37 @@ def test_awq_full_size_config3_properties(dev):
         assert np.array_equal(lv, r.Qt.t().cpu().numpy())
         back = ops.scale_columns(r.scaled_weight, r.smoothing_scales, divide=True)
         assert float((back.float() - w.float()).abs().max()) <= 2 ** -7 * float(w.float().abs().max())
+
+
+def test_awq_losses_batched_equals_per_point_calls(dev):
+    """qt_awq_losses (all grid points of a balance Linear in one Gram launch) against n_grid qt_awq_loss calls:
+    the same work items in the same order per grid point, so the losses are bit-identical; accumulate adds."""
+    from quantool_amd.hip import ops
+
+    g = torch.Generator(device=dev).manual_seed(21)
+    R, K, n_grid, n_tokens = 192, 512, 7, 1000
+    W = (torch.randn((R, K), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    X = torch.randn((n_tokens + 24, K), generator=g, device=dev).to(torch.bfloat16)
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    G = (torch.tril(G) + torch.tril(G, -1).t()).contiguous()
+    scales = (0.5 + torch.rand((n_grid, K), generator=g, device=dev)).contiguous()
+    one = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+    for i in range(n_grid):
+        ops.awq_loss(W, scales[i].contiguous(), 128, True, 4, G, n_tokens, one[i:i + 1], weight=0.25)
+    many = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+    ops.awq_losses(W, scales, 128, True, 4, G, n_tokens, many, weight=0.25)
+    torch.cuda.synchronize()
+    assert torch.equal(one, many) and bool((many > 0).all())
+    ops.awq_losses(W, scales, 128, True, 4, G, n_tokens, many, weight=0.25, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(many, 2 * one, rtol=1e-6, atol=0)
+    # a layout the batched form does not take (R % 64 != 0) goes through the per-point path with the same result
+    W2 = W[:100].contiguous()
+    a = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+    ops.awq_losses(W2, scales, 128, True, 4, G, n_tokens, a)
+    b = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+    for i in range(n_grid):
+        ops.awq_loss(W2, scales[i].contiguous(), 128, True, 4, G, n_tokens, b[i:i + 1])
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
