@@ -928,9 +928,21 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 }
 }  // namespace
 
+// The plan of one problem; with several problems in the launch the tiles alone fill the chip, so no tile is cut
+// into token chunks (every extra item is another epilogue that reads a 256 KiB tile of H)
+static XtxPlan xtx_frobenius_plan(int64_t n_tokens, int K, int n_batch) {
+    XtxPlan pl = xtx_plan(n_tokens, K);
+    if ((int64_t)pl.n_tiles * n_batch >= 4 * NUM_CU) {
+        pl.n_direct = pl.n_tiles;
+        pl.n_rem = 0;
+        pl.s2 = 1;
+    }
+    return pl;
+}
+
 size_t qt_xtx_frobenius_workspace_bytes(int64_t n_tokens, int K, int n_batch) {
     if (n_tokens <= 0 || K <= 0 || n_batch <= 0) return 0;
-    XtxPlan pl = xtx_plan(n_tokens, K);
+    XtxPlan pl = xtx_frobenius_plan(n_tokens, K, n_batch);
     const size_t grid = ((size_t)pl.n_direct + (size_t)pl.n_rem * pl.s2) * n_batch;
     return pl.tab_bytes + qt_align_up(grid * sizeof(double), 256) + 256;
 }
@@ -942,7 +954,7 @@ int qt_xtx_frobenius(const void* X, int x_dtype, int64_t n_tokens, int K, int64_
         ((uintptr_t)X & 15) != 0 || (uint64_t)ldx * 2 * UT + (uint64_t)K * 2 >= ((uint64_t)1 << 32) || n_batch <= 0 ||
         (n_batch > 1 && (x_batch_stride * 2) % 16 != 0))
         return QT_ERR_UNSUPPORTED;
-    XtxPlan pl = xtx_plan(n_tokens, K);
+    XtxPlan pl = xtx_frobenius_plan(n_tokens, K, n_batch);
     const int items = pl.n_direct + pl.n_rem * pl.s2;
     if ((int64_t)items * n_batch > (int64_t)1 << 30) return QT_ERR_UNSUPPORTED;
     const size_t need = qt_xtx_frobenius_workspace_bytes(n_tokens, K, n_batch);
