@@ -253,3 +253,25 @@ def test_awq_losses_batched_equals_per_point_calls(dev):
         ops.awq_loss(W2, scales[i].contiguous(), 128, True, 4, G, n_tokens, b[i:i + 1])
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_awq_losses_large_launch_agrees_with_per_point_calls(dev):
+    """>= 1024 tiles in the batched launch: tiles are no longer cut into token chunks, so a tile's fp32
+    accumulators run over all rows at once and the result differs from the per-point call's in rounding only.
+    Floating point: relative tolerance 2e-6 (fp32 partial sums of <= 512 terms, fp64 after that)."""
+    from quantool_amd.hip import ops
+
+    g = torch.Generator(device=dev).manual_seed(5)
+    R, K, n_grid, n_tokens = 512, 4096, 8, 4096
+    W = (torch.randn((R, K), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    A = torch.randn((K, K), generator=g, device=dev)
+    G = (A @ A.t()).contiguous()
+    scales = (0.5 + torch.rand((n_grid, K), generator=g, device=dev)).contiguous()
+    one = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+    for i in range(n_grid):
+        ops.awq_loss(W, scales[i].contiguous(), 128, True, 4, G, n_tokens, one[i:i + 1])
+    many = torch.zeros(n_grid, dtype=torch.float32, device=dev)
+    ops.awq_losses(W, scales, 128, True, 4, G, n_tokens, many)
+    torch.cuda.synchronize()
+    assert torch.allclose(many, one, rtol=2e-6, atol=0), (many, one)
+    assert int(torch.argmin(many)) == int(torch.argmin(one))
