@@ -229,6 +229,50 @@ def cpu_baseline_port():
     }
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this same command as
+    child processes, one per device (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+    rendezvous on 127.0.0.1), and return the worst exit code.  The parent never touches the GPU
+    (`device_count()` does not initialise it) and never re-execs itself.  Refuses when fewer than N
+    GPUs are visible instead of silently running a smaller job."""
+    import socket
+    import subprocess
+
+    if not REHEARSE:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to run a smaller job "
+                  f"(QT_BENCH_REHEARSE_GLOO=1 rehearses the N-rank control flow on one GPU)", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), QT_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:       # a rank died: the others would wait in a collective for ever
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +282,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
     ap.add_argument("--lanes", type=int, default=2, help="layers in flight (independent stream sets)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
+    ap.add_argument("--launch-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--method", choices=["gptq", "awq"], default="gptq",
                     help="gptq: the headline metric (BASELINE.json configs[1]); awq: configs[2], a second, separately "
                          "labelled line (20-point scale search + RTN + pack per decoder layer)")
@@ -248,11 +293,31 @@ def main():
                     help="activation ordering (default: upstream's default, static); other values are diagnostics")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become the launcher (nothing has touched the GPU yet)
+        raise SystemExit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: refusing to run a job of another size")
+    if args.launch_probe:
+        # CPU-side check of the launch path (tests/test_bench_launch.py): rendezvous over gloo, one
+        # all-reduce of the ranks, no GPU work, no benchmark line
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            dist_mod.all_reduce(t)
+            dist_mod.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "rank_sum": int(t.item()),
+                              "self_launched": os.environ.get("QT_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -320,6 +385,8 @@ def main():
     for _ in range(args.steps):
         kept.append(step(_))
     join_streams(dev)
+    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0          # this rank's own steps, before the collective
     if dist is not None:
         # final gather of the packed state to rank 0 (the job's only collective)
         from quantool_amd.engine.sharding import gather_state_dict
@@ -356,8 +423,13 @@ def main():
         iso_ms = t_iso.value
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if REHEARSE else dev)
+    per_rank = [t_compute]
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([t_compute], dtype=torch.float64, device=t_max.device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
     elapsed = float(t_max.item())
 
     weights_done = shape.weights_per_layer * args.steps * world
@@ -396,6 +468,8 @@ def main():
                        "quantized weights/sec (AWQ int4, Llama-3-8B, 512 calib samples) [BASELINE.json configs[2], not the headline]"),
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "per_rank_compute_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
+            "gather_ms": round((elapsed - max(per_rank)) * 1e3, 3) if world > 1 else 0.0,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {

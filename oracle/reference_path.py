@@ -155,6 +155,24 @@ def cholesky_inverse_upper_f64(Hd: np.ndarray) -> np.ndarray:
     return np.linalg.cholesky(Hinv).T.copy()
 
 
+def cholesky_inverse_upper_f64_lapack(Hd: np.ndarray) -> np.ndarray:
+    """The same fp64 'truth' through dpotrf / dpotri / dpotrf (4/3 K^3 flop instead of the dense
+    inverse and product of ``cholesky_inverse_upper_f64``): what the full-size factor tests use
+    at K = 8192 / 14336, where the numpy form would take minutes."""
+    from scipy.linalg import lapack
+
+    A = np.array(Hd, dtype=np.float64, order="F", copy=True)
+    c, info = lapack.dpotrf(A, lower=1, clean=1, overwrite_a=1)
+    assert info == 0, info
+    inv, info = lapack.dpotri(c, lower=1, overwrite_c=1)
+    assert info == 0, info
+    # potri fills the lower triangle only; the upper factorisation below reads the upper one, which
+    # in Fortran order is the transpose view of the lower triangle of the same buffer
+    u, info = lapack.dpotrf(np.asfortranarray(inv.T), lower=0, clean=1, overwrite_a=1)
+    assert info == 0, info
+    return np.ascontiguousarray(u)
+
+
 def cholesky_inverse_upper_ul(Hd: np.ndarray, dtype=np.float64) -> np.ndarray:
     """The algebraic shortcut the HIP path uses, restated on the CPU: with A = flip(H),
     A = R^T R (R upper), U = flip(R^-T).  Identical to the three-step sequence in exact

@@ -32,6 +32,9 @@ HIPCC_FLAGS = [
     "-Wno-unused-function",
 ]
 
+# lab builds: extra flags (e.g. QT_EXTRA_HIPCC_FLAGS=-DQT_XTX_ABLATION for tools/xtx_wrap_sweep.sh); part of the stamp
+HIPCC_FLAGS += os.environ.get("QT_EXTRA_HIPCC_FLAGS", "").split()
+
 
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):

@@ -71,7 +71,8 @@ struct XtxParams {
     int64_t x_batch_bytes;    // ... whose X matrices lie this many bytes apart
 };
 
-// WRAP = true is a TIMING-ONLY ablation (wrong results; QT_XTX_ABLATE_WRAP=<units>): the source
+// WRAP = true is a TIMING-ONLY ablation (wrong results; only in builds with -DQT_XTX_ABLATION, then
+// QT_XTX_ABLATE_WRAP=<units>): the source
 // pointer wraps every wrap_units units, so the footprint every workgroup streams is that window --
 // L2-resident for small windows, Infinity-Cache-resident for medium ones (profiles/r02_xtx_locality.md).
 //
@@ -804,10 +805,13 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
     p.dot_partials = nullptr;
     p.batch_items = 1;
     p.x_batch_bytes = 0;
+    p.wrap_units = 0;
+#ifdef QT_XTX_ABLATION   // lab builds only (tools/xtx_wrap_sweep.sh): the shipped library has no way into xtx_kernel<true>
     {
         const char* e = getenv("QT_XTX_ABLATE_WRAP");  // timing-only ablation, see xtx_kernel<true>
         p.wrap_units = e ? atoi(e) : 0;
     }
+#endif
     if (pl.has_tail) {
         const int64_t full = n_tokens / BKT * BKT;
         const int64_t tail_rows = n_tokens - full;
@@ -851,7 +855,10 @@ extern "C" int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, i
             qq.progress = nullptr;
             if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx16_kernel<true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
             else hipLaunchKernelGGL((xtx16_kernel<false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
-        } else if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+        }
+#ifdef QT_XTX_ABLATION
+        else if (q.wrap_units > 0) hipLaunchKernelGGL((xtx_kernel<true, false, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
+#endif
         else if (thr && x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         else if (thr) hipLaunchKernelGGL((xtx_kernel<false, false, true>), dim3(grid), dim3(NTHREADS), 0, stream, qq);
         else if (x_dtype == QT_F16) hipLaunchKernelGGL((xtx_kernel<false, true, false>), dim3(grid), dim3(NTHREADS), 0, stream, qq);

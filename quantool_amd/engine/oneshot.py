@@ -202,6 +202,16 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
 
             mine = {f"{n}::{k}": v for n, r in results.items() if plan_owner_is(plan, cal, n, rank)
                     for k, v in result_tensors(r).items()}
+            # the SmoothQuant stage's outputs travel with the owner's results: the rescaled producer vectors
+            # (norm weight / bias divided by s) and the scales exist only where `_smooth_group` ran, and rank 0
+            # must not save W*s for a group without its v/s
+            for g in cal.groups:
+                kind, owner = plan[g.name]
+                if (owner if kind == "A" else 0) != rank or g.name not in smoothing_scales:
+                    continue
+                mine[f"{g.name}::@smoothing_scale"] = smoothing_scales[g.name]
+                for vn in g.smooth_vectors:
+                    mine[f"{vn}::@smoothed"] = smoothed[vn]
             if torch.distributed.get_backend() == "gloo":     # host-side backend (CPU rehearsals): ship host tensors
                 mine = {k: v.cpu() for k, v in mine.items()}
                 merged = gather_state_dict(mine, dst=0, device=None)
@@ -211,7 +221,12 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
                 by_lin: Dict[str, dict] = {}
                 for key, t in merged.items():
                     n, k = key.split("::")
-                    by_lin.setdefault(n, {})[k] = t.to(device)
+                    if k == "@smoothing_scale":
+                        smoothing_scales.setdefault(n, t.to(device))
+                    elif k == "@smoothed":
+                        smoothed.setdefault(n, t.to(device))
+                    else:
+                        by_lin.setdefault(n, {})[k] = t.to(device)
                 for n, parts in by_lin.items():
                     if n not in results:
                         if "weight" in parts:
@@ -277,10 +292,11 @@ def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = N
             dataset_config_name: Optional[str] = None, text_column: str = "text", pad_to_max_length: bool = False,
             # upstream names that carry meaning here
             precision="auto", sequential_targets=None, pipeline: Optional[str] = None,
-            min_tokens_per_module: Optional[float] = None, calibrate_moe_context: bool = False,
             # upstream names accepted so that quantool routes them here instead of dropping them
             # (base.py:117-124 matches kwargs against this signature); they concern hub access, logging or
-            # sparsity stages, none of which exists in this backend
+            # sparsity stages or MoE calibration policy (experts are always calibrated on their routed tokens only),
+            # none of which exists in this backend
+            min_tokens_per_module: Optional[float] = None, calibrate_moe_context: bool = False,
             config_name=None, cache_dir=None, use_auth_token=False, tie_word_embeddings=False,
             model_revision: str = "main", recipe_args=None, clear_sparse_session: bool = False, stage=None,
             concatenate_data: bool = False, streaming: bool = False, overwrite_cache: bool = False,
@@ -299,7 +315,9 @@ def oneshot(model=None, dataset=None, recipe=None, output_dir: Optional[str] = N
     if pipeline not in (None, "sequential", "independent", "basic", "datafree"):
         raise ValueError(f"pipeline={pipeline!r}: expected 'sequential', 'independent', 'basic' or None")
     ignored = {k: v for k, v in dict(config_name=config_name, cache_dir=cache_dir, recipe_args=recipe_args, stage=stage,
-                                     log_dir=log_dir, tracing_ignore=tracing_ignore).items() if v not in (None, False)}
+                                     log_dir=log_dir, tracing_ignore=tracing_ignore,
+                                     min_tokens_per_module=min_tokens_per_module,
+                                     calibrate_moe_context=calibrate_moe_context).items() if v not in (None, False)}
     if ignored or unused:
         logger.info(f"oneshot: arguments without effect in this backend: {sorted(ignored) + sorted(unused)}")
     if recipe is None:

@@ -233,9 +233,10 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
         path = str(model)
         # the checkpoint's own dtype unless the caller says otherwise: the reference passes the model
         # path through with no dtype (base.py:222-241), upstream's `precision` defaults to "auto"
-        dt = {"auto": "auto", None: "auto", "float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
-              "bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "float32": torch.float32, "fp32": torch.float32,
-              "full": torch.float32}.get(precision if not isinstance(precision, torch.dtype) else None, precision)
+        table = {"auto": "auto", None: "auto", "float16": torch.float16, "fp16": torch.float16, "half": torch.float16,
+                 "bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "float32": torch.float32, "fp32": torch.float32,
+                 "full": torch.float32}
+        dt = precision if isinstance(precision, torch.dtype) else table.get(precision, precision)
         model = AutoModelForCausalLM.from_pretrained(path, dtype=dt, trust_remote_code=trust_remote_code,
                                                      local_files_only=True)
         if tokenizer is None:
@@ -335,7 +336,18 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 key = (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()))
                 groups.setdefault(key, []).append(n)
             seen.clear()
-            leaders = {names[0]: names for names in groups.values()}
+            grouping = list(groups.values())
+            if world > 1:
+                # every rank discovered the sharing on ITS batch 0, and a Linear one rank's batch did not reach
+                # (a sparse-MoE expert) would be a solo group there only: the ranks would then issue different
+                # all-reduce sequences.  Rank 0's grouping is everybody's (a solo group is always valid: it
+                # only forgoes the sharing).
+                import torch.distributed as dist
+
+                box = [grouping]
+                dist.broadcast_object_list(box, src=0)
+                grouping = box[0]
+            leaders = {names[0]: names for names in grouping}
             accs = {lead: HessianAccumulator(linears[lead].in_features, dev) for lead in leaders}
             # upstream counts one sample per forward of a batch-size-1 pipeline (num_added); with several samples
             # per forward a [B, T, K] input counts B, and a flattened [tokens, K] input (OPT's fc1, routed expert

@@ -39,19 +39,24 @@ def my_units(costs: Sequence[float], world: int, rank: int) -> List[int]:
     return [i for i, r in enumerate(lpt_assign(costs, world)) if r == rank]
 
 
-def _flatten(state: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, list]:
+def _flatten(state: Dict[str, torch.Tensor], device=None) -> Tuple[torch.Tensor, list]:
     """One byte buffer holding every tensor at a 16-byte aligned offset (a view of the buffer as the
-    tensor's dtype needs its offset divisible by the element size)."""
+    tensor's dtype needs its offset divisible by the element size).  The tensors may live on different
+    devices (``result_tensors`` keeps ``weight_shape`` on the host next to packed words on the GPU): each
+    is moved to ``device`` -- default: the first accelerator any of them is on, else the host -- before
+    the one concatenation."""
     meta, chunks, off = [], [], 0
-    dev = next(iter(state.values())).device if state else torch.device("cpu")
+    if device is None:
+        device = next((t.device for t in state.values() if t.device.type != "cpu"), torch.device("cpu"))
+    dev = torch.device(device)
     for name in sorted(state):
-        t = state[name].contiguous()
+        t = state[name].to(dev).contiguous()
         nbytes = t.numel() * t.element_size()
         meta.append((name, str(t.dtype).replace("torch.", ""), tuple(t.shape), off, nbytes))
         chunks.append(t.reshape(-1).view(torch.uint8))
         pad = (-nbytes) % 16
         if pad:
-            chunks.append(torch.zeros(pad, dtype=torch.uint8, device=t.device))
+            chunks.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
         off += nbytes + pad
     flat = torch.cat(chunks) if chunks else torch.empty(0, dtype=torch.uint8, device=dev)
     return flat, meta
@@ -72,9 +77,7 @@ def gather_state_dict(local: Dict[str, torch.Tensor], dst: int = 0, group=None, 
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    flat, meta = _flatten(local)
-    if device is not None:
-        flat = flat.to(device)
+    flat, meta = _flatten(local, device)
     metas = [None] * world
     dist.all_gather_object(metas, (meta, int(flat.numel())), group=group)
     # Posted as ONE batch so that RCCL runs the transfers as a group: the receives on ``dst`` then

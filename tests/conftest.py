@@ -31,3 +31,11 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def ops(dev):
+    """The ctypes layer over the C ABI (raises if the HIP library is missing)."""
+    from quantool_amd.hip import ops as _ops
+
+    return _ops

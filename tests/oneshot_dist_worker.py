@@ -76,6 +76,66 @@ def linears(rank, world, outdir):
     return ok
 
 
+def smooth(rank, world, outdir):
+    """SmoothQuant + GPTQ recipe over ranks: whole-unit (A) groups are smoothed on their owners only, so
+    the rescaled norm vectors and the scales must travel with the results -- rank 0's saved state has
+    to equal the single-process one tensor for tensor."""
+    from quantool_amd.engine.modifiers import GPTQModifier, SmoothQuantModifier
+    from quantool_amd.engine.oneshot import LinearCalibrationSet, LinearGroup, oneshot
+    from quantool_amd.engine.serialization import load_state
+    from quantool_amd.engine import sharding
+
+    dev = torch.device("cuda:0")
+
+    def build():
+        g = torch.Generator().manual_seed(33)
+
+        def acts(S, T, K):
+            x = torch.randn((S, T, K), generator=g)
+            x[..., 5] *= 8.0
+            return x.to(torch.bfloat16).to(dev)
+
+        def w(R, K):
+            return (torch.randn((R, K), generator=g) * 0.02).to(torch.bfloat16).to(dev)
+
+        def vec(K):
+            return (1.0 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev)
+
+        return [LinearGroup("down", acts(6, 128, 1024), {"down_proj": w(64, 1024)}),        # B, not smoothed
+                LinearGroup("attn", acts(6, 128, 256), {"q_proj": w(96, 256), "k_proj": w(32, 256)},
+                            smooth_vectors={"input_layernorm.weight": vec(256)}),
+                LinearGroup("mlp", acts(6, 128, 256), {"gate_proj": w(64, 256)},
+                            smooth_vectors={"post_attention_layernorm.weight": vec(256)})]
+
+    recipe = [SmoothQuantModifier(smoothing_strength=0.5), GPTQModifier(scheme="W4A16", targets="Linear", ignore=[])]
+    out = oneshot(model=LinearCalibrationSet(build()), recipe=recipe, output_dir=str(Path(outdir) / "dist"))
+    torch.cuda.synchronize()
+    dist.barrier()
+    ok = True
+    if rank == 0:
+        # the same job in one process: hide the process group from the engine
+        real = sharding.dist_world
+        sharding.dist_world = lambda: (1, 0)
+        try:
+            oneshot(model=LinearCalibrationSet(build()), recipe=recipe, output_dir=str(Path(outdir) / "single"))
+        finally:
+            sharding.dist_world = real
+        torch.cuda.synchronize()
+        a, b = load_state(str(Path(outdir) / "dist")), load_state(str(Path(outdir) / "single"))
+        ok &= set(a) == set(b)
+        ok &= {"input_layernorm.weight", "post_attention_layernorm.weight"} <= set(a)
+        for k in sorted(b):
+            if k.startswith("down_proj") and k.endswith("weight_packed"):
+                continue     # split group: Gram partials are added in rank order (covered by mode `linears`)
+            same = k in a and torch.equal(a[k], b[k])
+            if not same:
+                print(f"[smooth] {k}: differs", flush=True)
+            ok &= same
+        ok &= set(out.smoothing_scales) == {"attn", "mlp"}
+        print(f"[smooth] keys {len(a)} ok {ok}", flush=True)
+    return ok
+
+
 def module(rank, world, outdir):
     import quantool_amd.methods  # noqa: F401
     from transformers import LlamaConfig, LlamaForCausalLM
@@ -127,7 +187,7 @@ def main():
     mode, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        ok = linears(rank, world, outdir) if mode == "linears" else module(rank, world, outdir)
+        ok = {"linears": linears, "smooth": smooth, "module": module}[mode](rank, world, outdir)
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         sys.exit(0 if int(flag.item()) == 1 else 3)

@@ -168,3 +168,25 @@ def test_row_slices_cover_every_row_once():
         assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
         sizes = [e - b for b, e in sl]
         assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_flatten_mixed_dtypes_alignment_and_target_device():
+    """`_flatten` packs tensors of any dtype at 16-byte aligned offsets into one byte buffer on ONE device
+    (given, or inferred), so a dict like `result_tensors()` -- int32 words, bf16 scales, int8 zero-points,
+    int64 shape -- survives the trip (the mixed host/GPU case runs in test_gpu_oneshot_dist.py)."""
+    from quantool_amd.engine.sharding import _flatten, _unflatten
+
+    g = torch.Generator().manual_seed(3)
+    state = {"a.weight_packed": torch.randint(-2 ** 31, 2 ** 31 - 1, (5, 3), generator=g, dtype=torch.int32),
+             "a.weight_scale": torch.randn(5, 1, generator=g).to(torch.bfloat16),
+             "a.weight_zero_point": torch.randint(-8, 8, (5, 1), generator=g, dtype=torch.int8),
+             "a.weight_shape": torch.tensor([5, 24], dtype=torch.int64),
+             "a.weight_g_idx": torch.arange(24, dtype=torch.int32).t()}
+    flat, meta = _flatten(state, "cpu")
+    assert flat.dtype == torch.uint8 and all(off % 16 == 0 for _, _, _, off, _ in meta)
+    back = _unflatten(flat, meta)
+    assert set(back) == set(state)
+    for k, v in state.items():
+        assert back[k].dtype == v.dtype and torch.equal(back[k], v)
+    flat0, meta0 = _flatten({})
+    assert flat0.numel() == 0 and meta0 == []
