@@ -375,7 +375,7 @@ def main():
         from quantool_amd.engine.sharding import gather_state_dict
 
         gather_state_dict({f"warm.{rank}": torch.zeros(1 << 20, dtype=torch.uint8, device=dev)}, dst=0,
-                          device=None if REHEARSE else dev)
+                          device="cpu" if REHEARSE else dev)
     barrier()
 
     lib.qt_profile_enable(1)
@@ -392,7 +392,7 @@ def main():
         from quantool_amd.engine.sharding import gather_state_dict
 
         local = {f"layers.{rank + world * i}.{k}": v for i, outs in enumerate(kept) for k, v in outs.items()}
-        merged = gather_state_dict(local, dst=0, device=None if REHEARSE else dev)
+        merged = gather_state_dict(local, dst=0, device="cpu" if REHEARSE else dev)
         if rank == 0:
             assert len(merged) == len(local) * world
     barrier()

@@ -131,11 +131,7 @@ def convert_row(example: dict, tokenizer: Any, tools: Optional[List[Any]] = None
 
 
 def row_converter() -> Callable[..., dict]:
-    """quantool's own ``convert_row`` when the package is importable (so a quantool install keeps
-    its exact front-end), this module's otherwise."""
-    try:
-        from quantool.utils.dataset_textifier import convert_row as theirs
-
-        return theirs
-    except Exception:  # noqa: BLE001
-        return convert_row
+    """The row converter the plugins use: always this module's (its outputs are pinned against quantool's own
+    ``convert_row`` by the reference-generated fixtures, ``tests/golden/boundary_reference.json``), so the front-end
+    does not change with what happens to be installed next to it."""
+    return convert_row

@@ -26,13 +26,13 @@ from .test_gpu_fullsize_oracle import _gpu_run
 
 pytestmark = pytest.mark.gpu
 
-# K -> (rows of the slice, calibration samples of 384 tokens, actorder, bound on the nibble mismatch rate)
+# K -> rows of the slice, calibration samples of 384 tokens, seed
 CASES = {
-    8192: dict(R=256, n_samples=96, seed=23, bound=None),
-    14336: dict(R=256, n_samples=128, seed=29, bound=None),
+    8192: dict(R=256, n_samples=96, seed=23),
+    14336: dict(R=256, n_samples=128, seed=29),
 }
 # observed rates; the asserted bound is 10x the observation, floor 2e-5
-OBSERVED = {8192: None, 14336: None}
+OBSERVED = {8192: 0.0, 14336: 1.25e-4}     # round 3, 256-row slices: 0 of 2 097 152 and 459 of 3 670 016 nibbles
 
 
 @pytest.fixture(scope="module", params=sorted(CASES))

@@ -70,7 +70,17 @@ def test_q_proj_size_bit_exact_given_gpu_factor_and_lapack_rate(dev, oracle):
     rate = float((q_gpu != o2["q"]).mean())
     print(f"\n[fullsize] q_proj 4096x4096: nibble mismatch rate vs LAPACK-factor oracle = {rate:.3e}")
     np.testing.assert_array_equal(res.scale_f32.cpu().numpy(), o2["scale"])
-    assert rate <= 1e-4      # observed 9.0e-6 (151 of 16.8 M nibbles); the bound is ~10x it
+    # yardstick: two CPU factorisations of the same matrix (fp64 three-step rounded to fp32 vs fp32 LAPACK)
+    Hp = H[o2["perm"]][:, o2["perm"]]
+    U64 = oracle.cholesky_inverse_upper_f64_lapack(oracle.hessian_dead_and_damp(Hp, 0.01)[0]).astype(np.float32)
+    o3 = oracle.quantize_weight(Wf, H, actorder="static", U_override=U64)
+    rate64 = float((o3["q"] != o2["q"]).mean())
+    print(f"[fullsize] q_proj 4096x4096: fp64-factor oracle vs LAPACK-factor oracle = {rate64:.3e}")
+    # observed 2.5e-5 on the round-2/3 code (421 of 16.8 M nibbles; 9.0e-6 before the K = 4096
+    # Gram passes moved to the 16x16x32 kernel -- the count moves with any change of a summation order);
+    # the bound is 10x the observation, and a few times the distance between the two CPU factorisations
+    assert rate <= 2.5e-4
+    assert rate <= max(5 * rate64, 2e-5), (rate, rate64)
 
 
 def test_q_proj_size_group_actorder_asymmetric(dev, oracle):
