@@ -73,15 +73,15 @@ class HipCompressorQuantizer(BaseQuantizer):
     @classmethod
     def _get_oneshot_params(cls) -> set:
         """The engine's keyword names, by introspection (reference ``base.py:45-72``)."""
-        if cls._ONESHOT_PARAMS_CACHE is not None:
-            return cls._ONESHOT_PARAMS_CACHE
+        if HipCompressorQuantizer._ONESHOT_PARAMS_CACHE is not None:
+            return HipCompressorQuantizer._ONESHOT_PARAMS_CACHE
         names: set = set()
         try:
             sig = inspect.signature(cls._import_oneshot_static())
             names = {n for n in sig.parameters if n not in ("self", "unused")}
         except Exception as exc:  # noqa: BLE001 - routing degrades to "nothing is an engine kwarg"
             logging.getLogger(__name__).warning(f"oneshot signature unavailable ({exc}); no keyword is routed to it")
-        cls._ONESHOT_PARAMS_CACHE = names
+        HipCompressorQuantizer._ONESHOT_PARAMS_CACHE = names   # one cache for all plugins, on the base class
         return names
 
     # ---------------------------------------------------------------- calibration hooks
