@@ -8,10 +8,18 @@ inputs, Hessian prepare, Cholesky-inverse factor, the GPTQ block sweep (actorder
 upstream default) and int4 pack.  `--steps 32` is the whole 8B model.  Inputs (synthetic weights
 and activations) are resident in HBM before the timed region.
 
+Other BASELINE.json configs, each a SEPARATELY LABELLED line (its own `metric` string, never the headline):
+  --method awq                 configs[2]: Llama-3-8B AWQ int4 g128 (20-point scale search + RTN + pack)
+  --model llama-3-70b          configs[3]: one Llama-3-70B-shaped decoder layer per step (hidden 8192, inter 28672:
+                               the K = 28672 down_proj group on one GPU), GPTQ int4 g128
+  --model mixtral-8x7b         configs[4]: one Mixtral-8x7B-shaped decoder layer per step: attention + 8 experts whose
+                               tokens come from a seeded top-2 router (ragged token counts), SmoothQuant on the
+                               attention inputs + GPTQ int4 g128 (W4A8 preset) on every Linear, experts included
+
 Multi-GPU: decoder layers are independent units in this synthetic per-Linear mode, so every rank
 quantizes its own layers (weak scaling, no data-path collective) and rank 0 gathers the packed
 state over RCCL at the end of the timed region (north_star: "RCCL ... only to gather the final
-quantized state_dict").
+quantized state_dict").  `python bench.py --gpus N` starts its own N ranks when no launcher did.
 
 Prints ONE JSON line on rank 0.
 """
@@ -35,7 +43,6 @@ import torch  # noqa: E402
 
 N_SAMPLES = 512
 SEQ_LEN = 384
-MODEL = "llama-3-8b"
 REHEARSE = os.environ.get("QT_BENCH_REHEARSE_GLOO") == "1"   # see main(): N>1 control flow on a one-GPU box
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
@@ -95,7 +102,23 @@ def accumulate(acc, X, n_samples, per_sample):
     acc.flush()
 
 
-def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0, per_sample=False):
+def smooth_group(lins, weights, X, norm_vec, alpha=0.5):
+    """SmoothQuant stage of a mapping (reference smoothquant.py:77-84): channel min/max of the
+    producer's output over all tokens, s = range^a / max|W|^(1-a), balance weights * s, producer vector / s,
+    and what the smoothed producer now emits: X / s.  Returns (weights by name, X / s)."""
+    from quantool_amd.engine.smoothquant import ChannelMinMax, apply_smoothing, smoothquant_scales
+    from quantool_amd.hip import ops
+
+    K = X.shape[1]
+    stats = ChannelMinMax(K, X.device)
+    stats.add(X)
+    ws = [weights[n] for n, _ in lins]
+    s = smoothquant_scales(stats, ws, alpha)
+    new_w, _ = apply_smoothing(s, ws, [norm_vec])
+    return dict(zip((n for n, _ in lins), new_w)), ops.scale_columns(X, s, divide=True)
+
+
+def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0, per_sample=False, smooth=None):
     """One step: the hot path over one decoder layer.  Returns the packed outputs.
 
     The layer's Linear groups are independent, so each runs on its own HIP stream: the
@@ -113,7 +136,7 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
         if overlap:
             # stream slots per layer: "all4" = one per group; "two" = the largest-K group alone, the rest
             # share one stream (diagnostic knob; default all4)
-            slot = gi if os.environ.get("QT_BENCH_GROUPING", "all4") == "all4" else min(gi, 1)
+            slot = gi % 4 if os.environ.get("QT_BENCH_GROUPING", "all4") == "all4" else min(gi, 1)
             if (dev.index, lane, slot) not in _STREAMS:
                 # QT_BENCH_CHAIN_PRIO=1 (diagnostic): the chain streams at high priority
                 prio = -1 if os.environ.get("QT_BENCH_CHAIN_PRIO") == "1" else 0
@@ -134,14 +157,17 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
             sx.wait_stream(main)
             with torch.cuda.stream(sx):
                 acc = HessianAccumulator(K, dev)   # fresh: its later use is on another stream
-                accumulate(acc, acts[gname], n_samples, per_sample)
+                accumulate(acc, acts[gname], n_samples, per_sample)   # (diagnostic stream policies: no smoothing stage)
             acc.G.record_stream(st)
             st.wait_stream(sx)
         with torch.cuda.stream(st):
+            X, wts = acts[gname], weights
+            if smooth and gname in smooth:
+                wts, X = smooth_group(lins, weights, X, smooth[gname])
             if xmode == "group":
-                acc = _accumulator(K, dev, lane, gi)
-                accumulate(acc, acts[gname], n_samples, per_sample)
-            res = gptq_quantize_shared([weights[n] for n, _ in lins], acc, qargs)
+                acc = _accumulator(K, dev, lane, gi % 4)
+                accumulate(acc, X, n_samples, per_sample)
+            res = gptq_quantize_shared([wts[n] for n, _ in lins], acc, qargs)
             for (lname, _), r in zip(lins, res):
                 outs[f"{lname}.weight_packed"] = r.weight_packed
                 outs[f"{lname}.weight_scale"] = r.weight_scale
@@ -161,6 +187,46 @@ def awq_layer(shape, weights, acts, qargs):
             outs[f"{lname}.weight_packed"] = r.weight_packed
             outs[f"{lname}.weight_scale"] = r.weight_scale
     return outs
+
+
+def stage_split(shape, weights, acts, n_samples, smooth=None):
+    """Per-stage device time of one step with NOTHING overlapped (one stream, stage after stage, torch events),
+    outside the timed region: where a layer's time goes when the streams do not hide the latency-bound chains.
+    The sum is therefore larger than `ms_per_step`."""
+    from quantool_amd.hip import ops
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1)
+
+    tot = {}
+    for gname, K, lins in shape.groups:
+        X = acts[gname]
+        wts = weights
+        row = {}
+        if smooth and gname in smooth:
+            (wts, X), row["smooth"] = timed(lambda: smooth_group(lins, weights, X, smooth[gname]))
+        Ws = [wts[n] for n, _ in lins]
+        W = torch.cat(Ws, 0) if len(Ws) > 1 else Ws[0]
+        G = torch.zeros((K, K), dtype=torch.float32, device=X.device)
+        _, row["gram"] = timed(lambda: ops.xtx_accumulate(X, G))
+        diag = ops.hessian_diag(G, n_samples)
+        (perm, inv), row["order"] = timed(lambda: ops.argsort_desc(diag))
+        (A, dead, _), row["prepare"] = timed(lambda: ops.hessian_prepare(G, n_samples, 0.01, perm))
+        (U, info), row["factor"] = timed(lambda: ops.cholesky_inverse_upper(A))
+        Wf, row["gather"] = timed(lambda: ops.weight_gather_f32(W, perm, dead))
+        (sc, zp, sct, zpt), row["qparams"] = timed(lambda: ops.group_minmax_qparams(W, 128, True, 4))
+        g_sweep = (torch.arange(K, device=X.device, dtype=torch.int32) // 128)[perm.long()].contiguous()
+        (Qt, loss), row["sweep"] = timed(lambda: ops.gptq_sweep(Wf, U, sct, zpt, g_sweep, 128, 4))
+        _, row["pack"] = timed(lambda: ops.pack_int4(Qt, inv))
+        for k, v in row.items():
+            tot[k] = tot.get(k, 0.0) + v
+        del G, A, U, Wf, Qt, W
+    return {k: round(v, 3) for k, v in tot.items()}
 
 
 def join_streams(dev):
@@ -279,10 +345,15 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-split", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
     ap.add_argument("--lanes", type=int, default=2, help="layers in flight (independent stream sets)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--launch-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--model", choices=["llama-3-8b", "llama-3-70b", "mixtral-8x7b"], default="llama-3-8b",
+                    help="llama-3-8b: the headline (BASELINE.json configs[1]); llama-3-70b: configs[3], one 70B-shaped decoder "
+                         "layer per step; mixtral-8x7b: configs[4], one Mixtral-shaped layer per step (seeded top-2 routing, "
+                         "SmoothQuant + GPTQ).  Anything but the default prints its own, separately labelled metric")
     ap.add_argument("--method", choices=["gptq", "awq"], default="gptq",
                     help="gptq: the headline metric (BASELINE.json configs[1]); awq: configs[2], a second, separately "
                          "labelled line (20-point scale search + RTN + pack per decoder layer)")
@@ -340,16 +411,41 @@ def main():
     from quantool_amd.hip import _lib
 
     lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
-    shape = MODEL_SHAPES[MODEL]
+    shape = MODEL_SHAPES[args.model]
+    if args.method == "awq" and args.model != "llama-3-8b":
+        raise SystemExit("--method awq is BASELINE.json configs[2]: Llama-3-8B only")
     n_tokens = args.samples * SEQ_LEN
     qargs = QuantArgs(num_bits=4, symmetric=True, group_size=128,
                       actorder=None if args.actorder == "none" else args.actorder)
 
-    weights, acts = {}, {}
+    weights, acts, smooth = {}, {}, None
+    route_counts = None
+    if args.model == "mixtral-8x7b":
+        # tokens reach an expert through a seeded top-2 router: ~N/4 tokens per expert, ragged
+        g = torch.Generator(device=dev)
+        g.manual_seed(7 + 1000 * rank)
+        top2 = torch.randn((n_tokens, 8), generator=g, device=dev).topk(2, dim=1).indices
+        route = [torch.nonzero((top2 == e).any(dim=1)).flatten() for e in range(8)]
+        route_counts = [int(r.numel()) for r in route]
+        x_moe = synth_activations(n_tokens, 4096, seed=5 + 1000 * rank, device=dev)
     for gi, (gname, K, lins) in enumerate(shape.groups):
-        acts[gname] = synth_activations(n_tokens, K, seed=2 + 17 * gi + 1000 * rank, device=dev)
+        if gname.startswith("expert"):
+            e = int(gname[len("expert"):].split("_")[0])
+            if gname.endswith("_in"):
+                acts[gname] = x_moe[route[e]].contiguous()      # the expert's routed rows of the MoE input
+            else:
+                acts[gname] = synth_activations(route_counts[e], K, seed=2 + 17 * gi + 1000 * rank, device=dev)
+        else:
+            acts[gname] = synth_activations(n_tokens, K, seed=2 + 17 * gi + 1000 * rank, device=dev)
         for li, (lname, R) in enumerate(lins):
             weights[lname] = synth_weight(R, K, seed=100 * gi + li + 1000 * rank, device=dev)
+    if args.model == "mixtral-8x7b":
+        del x_moe
+        # SmoothQuant stage: q/k/v <- input_layernorm (upstream's Mixtral mapping smooths attention and the router
+        # only; experts are quantised un-smoothed)
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        smooth = {"attn_in": (1.0 + 0.1 * torch.randn(4096, generator=g, device=dev)).to(torch.bfloat16)}
     torch.cuda.synchronize()
 
     def barrier():
@@ -364,7 +460,7 @@ def main():
         if awq:
             return awq_layer(shape, weights, acts, qargs)
         return quantize_layer(shape, weights, acts, qargs, args.samples, overlap=not args.no_overlap,
-                              lane=i % max(1, args.lanes), per_sample=per_sample)
+                              lane=i % max(1, args.lanes), per_sample=per_sample, smooth=smooth)
 
     for _ in range(args.warmup):
         step(_)
@@ -410,11 +506,14 @@ def main():
         from quantool_amd.hip import ops as _ops
 
         lib.qt_profile_enable(1)
-        for gname, K in {(g, K) for g, K, _ in shape.groups if g in ("attn_in", "mlp_down")}:
+        by_k = {}
+        for gname, K, _ in shape.groups:      # one group per distinct in_features: the first (full token count)
+            by_k.setdefault(K, gname)
+        for K, gname in by_k.items():
             Gtmp = torch.zeros((K, K), dtype=torch.float32, device=dev)
             for _ in range(2):
                 _ops.xtx_accumulate(acts[gname], Gtmp)
-                iso_flops += n_tokens * K * (K + 1)
+                iso_flops += acts[gname].shape[0] * K * (K + 1)
             torch.cuda.synchronize()
             del Gtmp
         t_iso, n_iso = ctypes.c_double(), ctypes.c_int64()
@@ -437,8 +536,8 @@ def main():
 
     # roofline of the dominant kernel (xtx_kernel): algorithmic flops N*K*(K+1) per Hessian
     # (symmetric minimum) / device time of the kernel from HIP events on its stream
-    alg_flops = sum(n_tokens * K * (K + 1) for _, K, _ in shape.groups) * args.steps
-    alg_bytes = sum(n_tokens * K * 2 + K * K * 4 for _, K, _ in shape.groups) * args.steps
+    alg_flops = sum(acts[g].shape[0] * K * (K + 1) for g, K, _ in shape.groups) * args.steps
+    alg_bytes = sum(acts[g].shape[0] * K * 2 + K * K * 4 for g, K, _ in shape.groups) * args.steps
     if awq:   # + one D^T D Gram pass per grid point and balance Linear (rows play the tokens' part)
         alg_flops += sum(20 * R * K * (K + 1) for _, K, lins in shape.groups for _, R in lins) * args.steps
         alg_bytes += sum(20 * (R * K * 2 + K * K * 4) for _, K, lins in shape.groups for _, R in lins) * args.steps
@@ -446,26 +545,59 @@ def main():
     roofline = {
         "kernel": "xtx_kernel / xtx16_kernel (the Gram kernel on its two MFMA shapes)", "bound": "mfma", "achieved": round(achieved_tflops, 2),
         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_BF16_MFMA_TFLOPS, 4),
-        "traffic": pmc_traffic(),
+        "traffic": pmc_traffic() if (args.model == "llama-3-8b" and not awq) else None,
         "launches": int(launches.value), "avg_launch_ms": round(tot_ms.value / max(1, launches.value), 4),
         "hbm_GBps_algorithmic": round(alg_bytes / (tot_ms.value * 1e-3) / 1e9, 1) if tot_ms.value > 0 else 0.0,
         "achieved_isolated": round(iso_flops / (iso_ms * 1e-3) / 1e12, 2) if iso_ms > 0 else None,
         "frac_isolated": round(iso_flops / (iso_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if iso_ms > 0 else None,
-        "note": ("achieved/frac: live in the timed region, flop-weighted over the 4 Gram launches per step (3x "
-                 "K=4096, 1x K=14336); the groups of a layer and two layers run concurrently on separate "
-                 "streams, so a live launch shares the CUs with other kernels. *_isolated: the same launches "
-                 "(K=4096 and K=14336, 2 each) alone on the GPU right after the timed region. north_star's HBM "
-                 "figure is hbm_GBps_algorithmic; X^T X is MFMA-bound (SURVEY 8d)"),
+        "note": ("achieved/frac: live in the timed region, flop-weighted over the step's Gram launches (one per "
+                 "distinct input: " + ", ".join(f"{sum(1 for _, k, _ in shape.groups if k == K)}x K={K}"
+                                                for K in sorted({k for _, k, _ in shape.groups})) + "); the groups of "
+                 "a layer and two layers run concurrently on separate streams, so a live launch shares the CUs with "
+                 "other kernels. *_isolated: one launch per distinct K (2 repetitions) alone on the GPU right after "
+                 "the timed region. traffic: from the committed PMC profile of the Llama-3-8B workload (bench.py "
+                 "cannot run the profiler). north_star's HBM figure is hbm_GBps_algorithmic; X^T X is MFMA-bound "
+                 "(SURVEY 8d)"),
     }
 
+    stages = None
+    if rank == 0 and world == 1 and not awq and not args.no_stage_split:
+        stages = stage_split(shape, weights, acts, args.samples, smooth)
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not awq:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not awq and args.model == "llama-3-8b":
         cpu = cpu_baseline_port()
 
     if rank == 0:
+        wpl = shape.weights_per_layer
+        n_lin = sum(len(l) for _, _, l in shape.groups)
+        if awq:
+            metric = ("quantized weights/sec (AWQ int4, Llama-3-8B, 512 calib samples) "
+                      "[BASELINE.json configs[2], not the headline]")
+            workload = ("Llama-3-8B-shaped random-init AWQ int4 g128 (W4A16, 20-point per-channel scale search, "
+                        "duo scaling), 512 synthetic calib samples x 384 tokens, 1 decoder layer (4 mappings, "
+                        f"7 Linears, {wpl} weights) per step per GPU")
+        elif args.model == "llama-3-70b":
+            metric = ("quantized weights/sec (GPTQ int4, Llama-3-70B, 512 calib samples) "
+                      "[BASELINE.json configs[3] on one GPU, not the headline]")
+            workload = (f"Llama-3-70B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, dampening 0.01, "
+                        "block 128), 512 synthetic calib samples x 384 tokens, 1 decoder layer (hidden 8192, inter 28672; "
+                        f"{n_lin} Linears, {wpl} weights) per step per GPU")
+        elif args.model == "mixtral-8x7b":
+            metric = ("quantized weights/sec (SmoothQuant + GPTQ int4, Mixtral-8x7B, 512 calib samples) "
+                      "[BASELINE.json configs[4] on one GPU, not the headline]")
+            workload = (f"Mixtral-8x7B-shaped random-init SmoothQuant (q/k/v <- input norm, strength 0.5) + GPTQ int4 g128 "
+                        f"(W4A8 preset weights, actorder={args.actorder}) on every Linear incl. the 8 experts, 512 synthetic "
+                        "calib samples x 384 tokens routed top-2 by a seeded router (tokens per expert: "
+                        f"{min(route_counts)}..{max(route_counts)}), 1 decoder layer ({n_lin} Linears, {wpl} weights) "
+                        "per step per GPU")
+        else:
+            metric = "quantized weights/sec (GPTQ int4, Llama-3-8B, 512 calib samples)"
+            workload = (f"Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, "
+                        "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
+                        f"1 decoder layer (7 Linears, {wpl} weights) per step per GPU")
         line = {
-            "metric": ("quantized weights/sec (GPTQ int4, Llama-3-8B, 512 calib samples)" if not awq else
-                       "quantized weights/sec (AWQ int4, Llama-3-8B, 512 calib samples) [BASELINE.json configs[2], not the headline]"),
+            "metric": metric,
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "per_rank_compute_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
@@ -473,16 +605,12 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {
-                "workload": ((f"Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, "
-                              "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
-                              "1 decoder layer (7 Linears, 218103808 weights) per step per GPU") if not awq else
-                             ("Llama-3-8B-shaped random-init AWQ int4 g128 (W4A16, 20-point per-channel scale search, "
-                              "duo scaling), 512 synthetic calib samples x 384 tokens, 1 decoder layer (4 mappings, "
-                              "7 Linears, 218103808 weights) per step per GPU")),
+                "workload": workload, "model": args.model, "method": args.method,
                 "n_calibration_samples": args.samples, "seq_len": SEQ_LEN, "accumulate": args.accumulate,
                 "layers_per_step_per_gpu": 1, "sharding": f"layers over {world} rank(s), RCCL gather of packed state",
             },
             "roofline": roofline,
+            "stages_ms_isolated": stages,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -65,6 +65,8 @@ class HessianAccumulator:
         self.n += int(num_samples)
         if t == 0:
             return
+        if X2.dtype not in (torch.bfloat16, torch.float16):
+            ops.wide_activation_policy(X2.dtype)      # fp32 activations: rounded to bf16, loudly (or refused)
         if self.dtype is None:
             # the checkpoint's own dtype (the reference injects none, base.py:222-241); see ops.as_act16
             self.dtype = X2.dtype if X2.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16

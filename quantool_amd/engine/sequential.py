@@ -94,6 +94,48 @@ class _UnfusedExperts(nn.Module):
         return out
 
 
+def expert_bank_checkpoint_names(state: Dict[str, torch.Tensor], banks: Dict[str, "_UnfusedExperts"]) -> Dict[str, torch.Tensor]:
+    """Checkpoint names for what ``_UnfusedExperts`` holds (it exists for calibration only; no loader knows
+    its ``<bank>.experts.{e}.gate_up_proj`` modules).
+
+    Written instead, per expert ``e`` of bank ``<bank>`` (e.g. ``model.layers.3.mlp.experts``) -- the per-expert
+    Linear layout MoE checkpoints and their loaders use (Mixtral's ``experts.{e}.w1/w3/w2``, Qwen-MoE's
+    ``experts.{e}.gate_proj/up_proj/down_proj``), which a compressed-tensors ``Linear`` target can address:
+
+      ``<bank>.{e}.gate_proj.*`` / ``<bank>.{e}.up_proj.*``  rows ``[0, I)`` / ``[I, 2I)`` of the fused gate_up matrix:
+                                 GPTQ rows are independent given the factor, so packed words, scales, zero-points
+                                 split by rows exactly; ``weight_g_idx`` (per input column) is shared; ``weight_shape``
+                                 becomes ``[I, H]``
+      ``<bank>.{e}.down_proj.*``  unchanged
+
+    Dense (un-quantised or ``save_compressed=False``) expert weights are split the same way into
+    ``....gate_proj.weight`` / ``up_proj.weight`` / ``down_proj.weight``.  INTEGRATION.md section 4 documents it."""
+    out: Dict[str, torch.Tensor] = {}
+    for name, t in state.items():
+        bank = next((b for b in banks if name.startswith(b + ".experts.")), None)
+        if bank is None:
+            out[name] = t
+            continue
+        e, proj, leaf = name[len(bank) + len(".experts."):].split(".", 2)
+        if proj != "gate_up_proj":
+            out[f"{bank}.{e}.{proj}.{leaf}"] = t
+            continue
+        if leaf == "weight_g_idx":                      # per input column: both halves read the same columns
+            out[f"{bank}.{e}.gate_proj.{leaf}"] = t
+            out[f"{bank}.{e}.up_proj.{leaf}"] = t.clone()          # safetensors refuses tensors that share storage
+        elif leaf == "weight_shape":
+            half = torch.tensor([int(t[0]) // 2, int(t[1])], dtype=t.dtype)
+            out[f"{bank}.{e}.gate_proj.{leaf}"] = half
+            out[f"{bank}.{e}.up_proj.{leaf}"] = half.clone()
+        else:                                           # row-indexed: weight, weight_packed, weight_scale, weight_zero_point
+            if t.shape[0] % 2:
+                raise ValueError(f"{name}: {t.shape[0]} rows cannot be split into gate and up halves")
+            inter = t.shape[0] // 2
+            out[f"{bank}.{e}.gate_proj.{leaf}"] = t[:inter].contiguous()
+            out[f"{bank}.{e}.up_proj.{leaf}"] = t[inter:].contiguous()
+    return out
+
+
 def unfuse_expert_banks(model: nn.Module) -> int:
     """Replace every fused expert bank by ``_UnfusedExperts``; returns how many were replaced."""
     n = 0
@@ -200,6 +242,7 @@ def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = T
     meta = getattr(model, "_qt_meta", {})
     state: Dict[str, torch.Tensor] = {}
     quantized = set(results)
+    banks = {n: m for n, m in model.named_modules() if isinstance(m, _UnfusedExperts)}
     for name, t in model.state_dict().items():
         mod = name.rsplit(".", 1)[0]
         if mod in quantized and name.endswith(".weight") and save_compressed:
@@ -209,6 +252,8 @@ def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = T
         for mod, r in results.items():
             for k, v in result_tensors(r).items():
                 state[f"{mod}.{k}"] = v
+    if banks:
+        state = expert_bank_checkpoint_names(state, banks)
     base_cfg = model.config.to_dict() if hasattr(model, "config") and hasattr(model.config, "to_dict") else {}
     save_state(state, quantization_config(meta.get("weights", {}), meta.get("format", "pack-quantized"),
                                           meta.get("ignore", []), meta.get("input_activations")), save_directory, base_cfg,

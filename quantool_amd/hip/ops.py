@@ -6,6 +6,8 @@ assumption the kernels make is asserted on the host first).  No arithmetic happe
 """
 from __future__ import annotations
 
+import logging
+import os
 from typing import Optional
 
 import torch
@@ -43,12 +45,41 @@ def _act16(X: torch.Tensor, name: str) -> int:
     return QT_BF16 if X.dtype == torch.bfloat16 else QT_F16
 
 
+_FP32_ACT_WARNED = False
+
+
 def as_act16(X: torch.Tensor) -> torch.Tensor:
     """Activations as the kernels take them: the model's own 16-bit dtype, untouched.  Upstream
-    accumulates ``inp.float()``; bf16 and fp16 widen exactly, so nothing is lost.  fp32
-    activations (an fp32 checkpoint) are the one case that is narrowed: they are rounded to bf16
-    (range over mantissa: an fp16 cast could overflow on outlier channels) -- DESIGN.md section 2."""
-    return X if X.dtype in (torch.bfloat16, torch.float16) else X.to(torch.bfloat16)
+    accumulates ``inp.float()``; bf16 and fp16 widen exactly, so nothing is lost.
+
+    fp32 activations (an fp32 checkpoint) are the one case that is NARROWER than the reference: they are
+    rounded to bf16 for the Gram / statistics passes (range over mantissa: an fp16 cast could overflow on
+    outlier channels).  That downgrade is never silent: it is logged once per process, and with
+    ``QT_FP32_ACTIVATIONS=error`` it is refused (``ValueError``) so that a pipeline which must match an
+    fp32 reference run bit for bit cannot pick it up unnoticed.  Loading the model with ``precision="bf16"``
+    (upstream's own default for GPU runs) avoids the case altogether."""
+    if X.dtype in (torch.bfloat16, torch.float16):
+        return X
+    wide_activation_policy(X.dtype)
+    return X.to(torch.bfloat16)
+
+
+def wide_activation_policy(dtype) -> None:
+    """Log (once) or refuse the bf16 rounding of activations wider than 16 bits: see ``as_act16``."""
+    if dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"calibration activations must be floating point, got {dtype}")
+    global _FP32_ACT_WARNED
+    policy = os.environ.get("QT_FP32_ACTIVATIONS", "warn").lower()
+    if policy == "error":
+        raise ValueError(f"{dtype} calibration activations: this backend accumulates X^T X from 16-bit activations; "
+                         "load the model in bf16 / fp16 (oneshot(precision=...)) or unset QT_FP32_ACTIVATIONS=error to "
+                         "accept rounding them to bf16")
+    if not _FP32_ACT_WARNED:
+        _FP32_ACT_WARNED = True
+        logging.getLogger(__name__).warning(
+            f"{dtype} calibration activations are rounded to bf16 for the Gram / statistics passes (upstream accumulates "
+            "them in fp32): Hessians differ at the 2^-9 level per activation.  Load the model in bf16 / fp16 to calibrate "
+            "in its own dtype, or set QT_FP32_ACTIVATIONS=error to refuse")
 
 
 def _req(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None):

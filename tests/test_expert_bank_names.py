@@ -1,0 +1,88 @@
+"""Saving a model whose fused MoE expert banks were unfused for calibration: the checkpoint
+must not carry ``_UnfusedExperts``' internal module names; per-expert gate / up / down entries are written
+instead, the fused gate_up rows split in two (exact: rows are independent)."""
+import types
+
+import torch
+from torch import nn
+
+from quantool_amd.engine import sequential as sq
+from quantool_amd.engine.serialization import load_state
+
+E, H, I = 3, 16, 24
+
+
+class FusedExperts(nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.gate_up_proj = nn.Parameter(torch.randn(E, 2 * I, H, generator=g))
+        self.down_proj = nn.Parameter(torch.randn(E, H, I, generator=g))
+        self.act_fn = nn.SiLU()
+
+
+class Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.experts = FusedExperts()
+        self.norm = nn.LayerNorm(H)
+
+
+class Res:      # the fields result_tensors() reads
+    def __init__(self, R, K, g_idx=False):
+        g = torch.Generator().manual_seed(R * 1000 + K)
+        self.weight_packed = torch.randint(-2 ** 31, 2 ** 31 - 1, (R, K // 8), generator=g, dtype=torch.int32)
+        self.weight_q = None
+        self.weight_scale = torch.randn(R, 1, generator=g).to(torch.bfloat16)
+        self.weight_zero_point = torch.randint(-8, 8, (R, 1), generator=g, dtype=torch.int8)
+        self.weight_g_idx = torch.arange(K, dtype=torch.int32) if g_idx else None
+        self.weight_shape = torch.tensor([R, K], dtype=torch.int64)
+
+
+def _model():
+    m = nn.Module()
+    m.layers = nn.ModuleList([Block()])
+    fused = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert sq.unfuse_expert_banks(m) == 1
+    return m, fused
+
+
+def test_compressed_save_uses_per_expert_names(tmp_path):
+    m, _ = _model()
+    res = {}
+    for e in range(E):
+        res[f"layers.0.experts.experts.{e}.gate_up_proj"] = Res(2 * I, H, g_idx=True)
+        res[f"layers.0.experts.experts.{e}.down_proj"] = Res(H, I)
+    m._qt_results = res
+    m._qt_meta = {"weights": {"num_bits": 4}, "format": "pack-quantized", "ignore": []}
+    sq._save_compressed(m, str(tmp_path))
+    sd = load_state(str(tmp_path))
+    assert not any(".experts.experts." in k or "gate_up_proj" in k for k in sd), sorted(sd)
+    for e in range(E):
+        r = res[f"layers.0.experts.experts.{e}.gate_up_proj"]
+        p = f"layers.0.experts.{e}"
+        assert torch.equal(sd[f"{p}.gate_proj.weight_packed"], r.weight_packed[:I])
+        assert torch.equal(sd[f"{p}.up_proj.weight_packed"], r.weight_packed[I:])
+        assert torch.equal(sd[f"{p}.gate_proj.weight_scale"], r.weight_scale[:I])
+        assert torch.equal(sd[f"{p}.up_proj.weight_zero_point"], r.weight_zero_point[I:])
+        assert sd[f"{p}.gate_proj.weight_shape"].tolist() == [I, H] == sd[f"{p}.up_proj.weight_shape"].tolist()
+        assert torch.equal(sd[f"{p}.gate_proj.weight_g_idx"], r.weight_g_idx)
+        assert torch.equal(sd[f"{p}.up_proj.weight_g_idx"], r.weight_g_idx)
+        d = res[f"layers.0.experts.experts.{e}.down_proj"]
+        assert torch.equal(sd[f"{p}.down_proj.weight_packed"], d.weight_packed)
+        assert sd[f"{p}.down_proj.weight_shape"].tolist() == [H, I]
+        assert f"{p}.down_proj.weight_g_idx" not in sd
+    assert "layers.0.norm.weight" in sd
+
+
+def test_dense_save_splits_the_views_of_the_fused_storage(tmp_path):
+    m, fused = _model()
+    m._qt_results, m._qt_meta = {}, {}
+    sq._save_compressed(m, str(tmp_path), save_compressed=False)
+    sd = load_state(str(tmp_path))
+    gu, dn = fused["layers.0.experts.gate_up_proj"], fused["layers.0.experts.down_proj"]
+    for e in range(E):
+        assert torch.equal(sd[f"layers.0.experts.{e}.gate_proj.weight"], gu[e, :I])
+        assert torch.equal(sd[f"layers.0.experts.{e}.up_proj.weight"], gu[e, I:])
+        assert torch.equal(sd[f"layers.0.experts.{e}.down_proj.weight"], dn[e])
+    assert not any("gate_up_proj" in k for k in sd)
