@@ -73,7 +73,7 @@ def _compile(src: Path) -> Path:
 
 
 def audit_m0(src: Path) -> None:
-    """xtx.hip and gemm3_tn.hip write M0 from inline asm without restoring it (the LDS-DMA destination).  That is only
+    """xtx.hip, gemm3_tn.hip and sgemm_tn.hip write M0 from inline asm without restoring it (the LDS-DMA destination).  That is only
     sound while hipcc itself never touches M0 in that translation unit, so the device ISA is checked:
     every line that names m0 must sit inside an ;;#ASMSTART ... ;;#ASMEND block."""
     stamp = OBJ_DIR / (src.stem + ".m0audit")
@@ -104,7 +104,7 @@ def build(verbose: bool = False) -> Path:
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
-    for name in ("xtx.hip", "gemm3_tn.hip"):
+    for name in ("xtx.hip", "gemm3_tn.hip", "sgemm_tn.hip"):
         audit_m0(CSRC / name)
     newest = max(o.stat().st_mtime for o in objs)
     if not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:

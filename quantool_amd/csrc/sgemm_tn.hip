@@ -200,6 +200,254 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
             }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// sgemm_ring_kernel: MODE_SUB on an LDS-DMA ring, persistent over the launch's tiles.
+//
+// The register-staged kernel above runs the sweep's k = 512 far update at 66-73 % MFMA-busy (profiles/
+// r02_gemm_pmc.txt) and even an 8192-deep product at only ~80 %: every k-step ends in vmcnt(0) + ds_write +
+// __syncthreads (the next panel was requested one k-step earlier, so its latency is exposed whenever it
+// exceeds one k-step), fragment reads are waited for right in front of their MFMAs, and every workgroup
+// pays its C read, first-panel latency and store tail while its co-resident partner is in the same phase.
+// Here:
+//   * panels go global -> LDS by LDS-DMA (16 B per lane, one instruction per thread and panel) into a ring
+//     of RS = 4 stages of BK = 16 k-rows; stages are consumed in pairs: the next pair is requested while the
+//     current one is multiplied (32 MFMAs per wave of latency cover), with ONE raw barrier per pair;
+//   * a workgroup walks its tiles (blockIdx.x, + gridDim.x, ...) as ONE stream of stages: the ring never
+//     drains between tiles; a tile's C is loaded during its own second k-step (into the registers the
+//     previous tile's stores have just released) and is not needed before its first chain ends.
+// Wave -> output mapping, MFMA shape and k order are those of sgemm_tn_kernel<128, 128, MODE_SUB, *, 8>:
+// per output element the same ascending-k fmaf chain(s) from 0 and the same subtraction(s), so the results
+// are bit-identical (tests/test_gpu_sgemm.py compares the two kernels bit for bit).
+// Requirements (the caller falls back to the kernel above otherwise): MODE_SUB, k_mode FULL, M % 128 == 0 and
+// N % 128 == 0 (whole tiles only: no edge predicates anywhere), kdim % 32 == 0, kdim >= 64, chain_len % 32 == 0,
+// lda / ldb % 4 == 0, A / B 16-byte aligned, 16 * ld * 4 < 2^32, 32 * ldc * 4 < 2^31.
+constexpr int RBK = 16;                       // k rows per stage
+constexpr int RBM = 128, RBN = 128;
+constexpr int RS = 4;                         // ring stages
+constexpr int RSTAGE_BYTES = RBK * (RBM + RBN) * 4;   // 16 KiB: A panel then B panel
+
+struct RingArgs {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    const float* Cin; int64_t ldcin;
+    float* Cout; int64_t ldcout;
+    int M, N, kdim, chain_len;     // chain_len > 0
+    int tiles_n, n_tiles;          // n_tiles = tiles_m * tiles_n (upper_only: listed tiles only)
+    int upper_only;
+};
+
+__device__ __forceinline__ void glds16_one(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
+template <int NW>
+__device__ __forceinline__ void ring_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void sgemm_ring_kernel(RingArgs p) {
+    // the ring + 256 bytes per wave that swallow the C prefetch (below)
+    __shared__ __attribute__((aligned(16))) char ring[RS * RSTAGE_BYTES + 8 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int steps = p.kdim / RBK;                 // per tile
+    const int fold_every = p.chain_len / RBK;
+    const int my_tiles = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    const int total = my_tiles * steps;             // stages this workgroup streams
+
+    // tile it (0 .. my_tiles) of this workgroup -> (m0, n0)
+    auto tile_origin = [&](int it, int& m0, int& n0) {
+        const int t = (int)blockIdx.x + it * (int)gridDim.x;
+        int tm, tn;
+        if (p.upper_only) {
+            // tiles with tn >= tm, listed row by row: row tm holds tiles_n - tm of them (tiles_m == tiles_n)
+            int rem = t;
+            tm = 0;
+            while (rem >= p.tiles_n - tm) { rem -= p.tiles_n - tm; ++tm; }
+            tn = tm + rem;
+        } else {
+            tm = t / p.tiles_n;
+            tn = t - tm * p.tiles_n;
+        }
+        m0 = tm * RBM;
+        n0 = tn * RBN;
+    };
+
+    // DMA geometry: thread t moves 16 bytes of k row (t >> 5), columns 4 * (t & 31) .. + 3 of each panel; a wave's
+    // instruction writes 1 KiB = two whole 512-byte panel rows, so the LDS image is plain [k][128] per panel
+    const int drow = tid >> 5, dcol = (tid & 31) * 4;
+    const unsigned voffA = (unsigned)(((size_t)drow * (size_t)p.lda + dcol) * 4), voffB = (unsigned)(((size_t)drow * (size_t)p.ldb + dcol) * 4);
+    const unsigned ring_lds = (unsigned)(size_t)(QT_LDS char*)ring;
+    const unsigned dst_wave = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)wave * 1024u);
+    // The stream of stages is issued in order, so its position is kept incrementally (no division per stage: SALU
+    // work right behind a barrier is executed by every wave at once, with the MFMA pipe idle)
+    int is_it = 0, is_s = 0, is_g = 0;          // next stage to request: tile is_it, k-step is_s, stream index is_g
+    const float *is_a, *is_b;
+    {
+        int m0i, n0i;
+        tile_origin(0, m0i, n0i);
+        is_a = p.A + m0i;
+        is_b = p.B + n0i;
+    }
+    const size_t a_step = (size_t)RBK * p.lda, b_step = (size_t)RBK * p.ldb;
+    auto issue_next = [&]() {
+        const unsigned d = dst_wave + (unsigned)(is_g & (RS - 1)) * RSTAGE_BYTES;
+        glds16_one(voffA, is_a, d);
+        glds16_one(voffB, is_b, d + RBK * RBM * 4);
+        ++is_g;
+        if (++is_s == steps) {
+            is_s = 0;
+            ++is_it;
+            if (is_it < my_tiles) {
+                int m0i, n0i;
+                tile_origin(is_it, m0i, n0i);
+                is_a = p.A + m0i;
+                is_b = p.B + n0i;
+            }
+        } else {
+            is_a += a_step;
+            is_b += b_step;
+        }
+    };
+    static_assert((RS & (RS - 1)) == 0, "slot = stream index & (RS - 1)");
+
+    f32x16 acc[2], cpre[2];
+    // C addressing through buffer instructions: descriptor base = the wave's corner of the tile (scalar), soffset =
+    // row / sub-tile offset (scalar), voffset = ONE per-lane byte offset that never changes -- no 64-bit per-lane
+    // addresses (32 of them cost 64 registers and spill the C tile)
+    const int cvoff_in = (int)(((size_t)(4 * h) * (size_t)p.ldcin + (size_t)l31) * 4);
+    const int cvoff_out = (int)(((size_t)(4 * h) * (size_t)p.ldcout + (size_t)l31) * 4);
+    const int cstep_in = (int)((size_t)p.ldcin * 4), cstep_out = (int)((size_t)p.ldcout * 4);
+    // register r of a 32x32 accumulator is row (r & 3) + 8 (r >> 2) (+ 4 h): the per-lane offset walks the rows
+    // (+1 row, and +5 rows after every fourth), the sub-tile j is an immediate
+    auto load_c = [&](int m0, int n0) {
+        const int rw = m0 + wave_m * 32, cw = n0 + wave_n * 64;      // wave-uniform
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cin + (size_t)rw * p.ldcin + cw), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int soff = ((r & 3) + 8 * (r >> 2)) * cstep_in;      // scalar; the sub-tile j is an immediate
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                cpre[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cvoff_in + j * 128, soff, 0));
+        }
+    };
+    auto store_c = [&](int m0, int n0) {      // Cout = cpre - acc
+        const int rw = m0 + wave_m * 32, cw = n0 + wave_n * 64;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cout + (size_t)rw * p.ldcout + cw), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int soff = ((r & 3) + 8 * (r >> 2)) * cstep_out;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cpre[j][r] - acc[j][r]), rs, cvoff_out + j * 128, soff, 0);
+        }
+    };
+    // C prefetch: ONE LDS-DMA dword per lane touches all 64 128-byte lines of the wave's 32 x 64 corner of a tile
+    // (lane -> row lane >> 1, half lane & 1), pulling them towards L2 a pair-step before the real loads; the data goes
+    // to a scratch corner of LDS nobody reads (no register is written, so nothing can be clobbered when it lands).
+    // vmcnt is in order: the real C loads have to be complete one pair-step after their issue or they hold up the
+    // panel DMA behind them -- from HBM that is too short, from L2 it is not.
+    const unsigned touch_voff = (unsigned)(((size_t)(lane >> 1) * (size_t)p.ldcin + (size_t)(lane & 1) * 32) * 4);
+    const unsigned touch_dst = __builtin_amdgcn_readfirstlane(ring_lds + RS * RSTAGE_BYTES + (unsigned)wave * 256u);
+    auto touch_c = [&](int m0, int n0) {
+        const float* base = p.Cin + (size_t)(m0 + wave_m * 32) * p.ldcin + n0 + wave_n * 64;
+        asm volatile(
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dword %0, %1"
+            :
+            : "v"(touch_voff), "s"(base), "s"(touch_dst)
+            : "memory");
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    };
+
+    // prologue: first tile's C (older than every DMA), stages 0 and 1
+    int m0, n0;
+    tile_origin(0, m0, n0);
+    load_c(m0, n0);
+    issue_next();
+    issue_next();
+
+    // ONE barrier per PAIR of stages (32 MFMAs per wave between barriers: a barrier is a moment at which every wave
+    // of the workgroup has stopped feeding the MFMA pipe).  At the top of pair-step P the stages 2P and 2P + 1 were
+    // requested one pair-step ago; stages 2P + 2, 2P + 3 are requested right behind the barrier into the slots of
+    // pair P - 1, whose reads every wave finished before arriving here.
+    // vmcnt bookkeeping: vmcnt counts EVERY vector-memory operation of the wave in issue order (DMA, C loads, C
+    // stores), so "pair P has landed" = "everything is done except what was issued after pair P's request", and the
+    // only such operations are the C batch of the END of pair-step P - 1: a tile's 32 stores (+ the next tile's one
+    // prefetch instruction) at the end of its last pair-step, or the 32 loads of a tile (not the first: prologue) at the end of its FIRST pair-step, into the
+    // registers the previous tile's stores released one pair-step earlier.
+    const int nchains = steps / fold_every;
+    const int pairs_per_chain = fold_every / 2;
+    int batch_prev = 0;
+    int g = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+        for (int ch = 0; ch < nchains; ++ch) {
+            zero_acc();      // every chain starts from zero (its own accumulator live range: no copies at the loop edges)
+            for (int ps = 0; ps < pairs_per_chain; ++ps, g += 2) {
+                if (batch_prev == 33) ring_wait_vmcnt<33>();
+                else if (batch_prev == 32) ring_wait_vmcnt<32>();
+                else ring_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (g + 2 < total) {
+                    issue_next();
+                    issue_next();
+                }
+                batch_prev = 0;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const char* stage = ring + ((g + half) & (RS - 1)) * RSTAGE_BYTES;
+                    const float* As = (const float*)stage + wave_m * 32 + l31;
+                    const float* Bs = (const float*)(stage + RBK * RBM * 4) + wave_n * 64 + l31;
+#pragma unroll
+                    for (int kk = 0; kk < RBK / 2; ++kk) {
+                        const float a = As[(2 * kk + h) * RBM];
+                        const float b0 = Bs[(2 * kk + h) * RBN], b1 = Bs[(2 * kk + h) * RBN + 32];
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+                    }
+                }
+                if (ps == 0 && ch == 0 && it > 0) {
+                    // this tile's C into the C registers; first needed when this tile's first chain ends
+                    load_c(m0, n0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    batch_prev = 32;
+                }
+            }
+            if (ch + 1 < nchains) {
+                // end of a chain inside the tile: fold it into the C registers
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cpre[j][r] = cpre[j][r] - acc[j][r];
+            }
+        }
+        // last chain of the tile: C - chain, stored (the batch of the end of the tile's last pair-step)
+        store_c(m0, n0);
+        __builtin_amdgcn_sched_barrier(0);
+        batch_prev = 32;
+        if (it + 1 < my_tiles) {
+            tile_origin(it + 1, m0, n0);
+            touch_c(m0, n0);          // one more operation in this batch
+            batch_prev = 33;
+        }
+    }
+}
+
 // Cout = mode(Cin, sum_z slab[z]) in ascending z (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int M,
                                                             int N, const float* __restrict__ Cin, int64_t ldcin,
@@ -329,6 +577,34 @@ int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
             if (rc) return rc;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.N / 4 + 255) / 256 + 1, a.M), dim3(256), 0, stream,
                                (const float*)a.split_ws, splits, a.M, a.N, a.Cin, a.ldcin, a.Cout, a.ldcout, a.mode);
+            QT_LAUNCH_CHECK();
+            return QT_OK;
+        }
+    }
+    // MODE_SUB products with enough 128x128 tiles: the LDS-DMA ring kernel, persistent over its tiles
+    // (both knobs are read per call: the tests and A/B tools switch them inside one process)
+    const char* ring_env = getenv("QT_SGEMM_RING");
+    const int use_ring = (ring_env && atoi(ring_env) == 0) ? 0 : 1;
+    const char* ring_min_env = getenv("QT_SGEMM_RING_MIN_TILES");
+    const int ring_min_tiles = ring_min_env ? atoi(ring_min_env) : 384;
+    if (use_ring && a.mode == SG_MODE_SUB && a.k_mode == SG_K_FULL && a.k_chunk == 0 && a.kdim >= 4 * RBK &&
+        a.kdim % (2 * RBK) == 0 && (a.chain_len == 0 || (a.chain_len % (2 * RBK) == 0 && a.kdim % a.chain_len == 0)) &&
+        a.kdim % RBK == 0 && (a.chain_len == 0 || a.chain_len % RBK == 0) && a.M % RBM == 0 && a.N % RBN == 0 &&
+        (size_t)40 * (size_t)(a.ldcin > a.ldcout ? a.ldcin : a.ldcout) * 4 < ((size_t)1 << 31) && a.lda % 4 == 0 &&
+        a.ldb % 4 == 0 && (((uintptr_t)a.A | (uintptr_t)a.B) & 15) == 0 &&
+        (size_t)RBK * (size_t)(a.lda > a.ldb ? a.lda : a.ldb) * 4 < ((size_t)1 << 32) && (!a.upper_only || a.M == a.N)) {
+        RingArgs r;
+        r.A = a.A; r.lda = a.lda; r.B = a.B; r.ldb = a.ldb;
+        r.Cin = a.Cin; r.ldcin = a.ldcin; r.Cout = a.Cout; r.ldcout = a.ldcout;
+        r.M = a.M; r.N = a.N; r.kdim = a.kdim;
+        r.chain_len = a.chain_len > 0 ? a.chain_len : a.kdim;
+        const int tm = (a.M + RBM - 1) / RBM, tn = (a.N + RBN - 1) / RBN;
+        r.tiles_n = tn;
+        r.upper_only = a.upper_only;
+        r.n_tiles = a.upper_only ? tn * (tn + 1) / 2 : tm * tn;
+        if (r.n_tiles >= ring_min_tiles) {
+            const int grid = r.n_tiles >= 2 * 256 ? 2 * 256 : r.n_tiles;      // two workgroups per CU
+            hipLaunchKernelGGL(sgemm_ring_kernel, dim3(grid), dim3(512), 0, stream, r);
             QT_LAUNCH_CHECK();
             return QT_OK;
         }

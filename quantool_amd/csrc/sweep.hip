@@ -189,6 +189,224 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
     if (valid) loss[row] = loss[row] + blk_loss / 2.0f;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// sweep_quad_kernel: the same 128 sequential steps with FOUR LANES PER ROW.
+//
+// The row-per-lane kernel above is bound by what ONE wave can issue (a lone wave issues a VALU op every 4
+// cycles; per column: ~30 dependent ops of the quantise step + 2 ops per later column of the block), and a
+// launch has only R / 64 waves (64 waves for R = 4096 on a chip with 1024 SIMDs).  Here lane (r, p),
+// p = lane & 3, owns the block's columns 4m + p (m = 0..31) of row r, all 32 in registers: no weight tile
+// in LDS, no sub-blocks.  At step c = 4 m0 + p0 every lane of the quad runs the quantise step on its own
+// column-m0 register (only the owner's, p == p0, is final and kept), the owner's error is broadcast inside
+// the quad by one DPP move, and every lane updates its own later columns -- a quarter of the row's update
+// work per lane, four times the waves.  Per ELEMENT the operation sequence is unchanged: ascending source
+// column, each step  w = w - (err * u)  with two roundings, IEEE division, round-half-even -- so the
+// outputs are bit for bit those of the row-per-lane kernel and of oracle/gptq_oracle.c:orc_gptq_sweep.
+// The per-row loss is summed in column order too (every lane of a quad carries the same running sum).
+//
+// LDS: only the U block, laid out per (step c, lane class p): Up[c][p][m] = U[i1+c][i1+4m+p] for
+// 4m+p > c, else 0 (a lane reads its 32 - m0 values of a step as float4s; 36-float rows keep the four
+// classes of a quad on disjoint banks).  73 KiB per workgroup of 64 rows, so two workgroups share a CU
+// with room left for a GEMM workgroup.
+constexpr int QL = 4;                 // lanes per row
+constexpr int QROWS = 64;             // rows per workgroup
+constexpr int QTHREADS = QROWS * QL;  // 256
+constexpr int QM = BS / QL;           // columns per lane: 32
+constexpr int UP_P = QM + 4;          // floats per (c, p) row
+constexpr int UP_C = QL * UP_P;       // floats per step c
+constexpr size_t QUAD_LDS = (size_t)(BS * UP_C + 2 * BS) * sizeof(float);
+
+template <int P0>
+__device__ __forceinline__ float quad_bcast(float v) {
+    // every lane of a quad gets lane P0's value (DPP quad_perm [P0, P0, P0, P0])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), P0 * 0x55, 0xF, 0xF, true));
+}
+
+constexpr int QPF = 3;   // macro-steps (of 4 columns) a lane's scale / zero-point loads run ahead of their use
+
+struct QuadState {
+    float w[QM], sc[QM], zz[QM];   // sc / zz: only entries M0 .. M0 + QPF are live at macro-step M0
+    float lsum, qv, ev, dv;
+};
+
+template <int M0, int P0>
+__device__ __forceinline__ void quad_step(QuadState& s, const float* __restrict__ Up, const float* __restrict__ dd,
+                                          int p, float qmin, float qmax) {
+    constexpr int C = 4 * M0 + P0;
+    // this lane's U values of step C: columns 4m + p, m >= M0
+    float u[QM];
+    const f32x4* urow = (const f32x4*)(Up + C * UP_C + p * UP_P);
+#pragma unroll
+    for (int k4 = M0 >> 2; k4 < QM / 4; ++k4) {
+        const f32x4 t = urow[k4];
+        u[4 * k4 + 0] = t[0]; u[4 * k4 + 1] = t[1]; u[4 * k4 + 2] = t[2]; u[4 * k4 + 3] = t[3];
+    }
+    const float d = dd[C];
+    // the quantise step on this lane's own column-M0 value (final only in the owner lane)
+    const float wv = s.w[M0];
+    float x = wv / s.sc[M0];
+    x = x + s.zz[M0];
+    x = fminf(fmaxf(x, qmin), qmax);
+    const float q = rintf(x);
+    const float dq = (q - s.zz[M0]) * s.sc[M0];
+    const float diff = wv - dq;
+    const float e = diff / d;
+    const bool own = p == P0;
+    s.dv = own ? diff : s.dv;
+    s.qv = own ? q : s.qv;
+    s.ev = own ? e : s.ev;
+    const float eb = quad_bcast<P0>(e);
+    // column M0 of the lanes behind the owner; the owner's becomes the dequantised value; lanes before it keep theirs
+    {
+        const float pr = eb * u[M0];
+        const float t = s.w[M0] - pr;
+        s.w[M0] = p > P0 ? t : (own ? dq : s.w[M0]);
+    }
+    // every later column of this lane (two per instruction where a pair is available)
+    constexpr int MS = M0 + 1;
+    if (MS < QM && (MS & 1)) {
+        const float pr = eb * u[MS];
+        s.w[MS] = s.w[MS] - pr;
+    }
+    const f32x2 e2 = {eb, eb};
+#pragma unroll
+    for (int m = (MS + 1) & ~1; m < QM; m += 2) {
+        const f32x2 uu = {u[m], u[m + 1]};
+        const f32x2 pr = e2 * uu;
+        f32x2 wp = {s.w[m], s.w[m + 1]};
+        wp = wp - pr;
+        s.w[m] = wp[0];
+        s.w[m + 1] = wp[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep a step's LDS reads next to their use (register pressure)
+}
+
+struct QuadScales {
+    const float* scale_t;   // + rowc
+    const float* zp_t;      // + rowc
+    const int32_t* gcol;    // g_idx + i1 + p
+    int R, nm;
+};
+
+template <int M>
+__device__ __forceinline__ void quad_load_scales(QuadState& s, const QuadScales& q) {
+    if constexpr (M < QM) {
+        const int g = q.gcol[M < q.nm ? 4 * M : 0];
+        s.sc[M] = q.scale_t[(size_t)g * q.R];
+        s.zz[M] = q.zp_t[(size_t)g * q.R];
+    }
+}
+
+template <int M0>
+__device__ __forceinline__ void quad_macro_step(QuadState& s, const QuadScales& qs, const float* __restrict__ Up,
+                                                const float* __restrict__ dd,
+                                                int p, float qmin, float qmax, bool valid, int row, int R, int i1,
+                                                int8_t* __restrict__ Qt, float* __restrict__ ErrT) {
+    quad_load_scales<M0 + QPF>(s, qs);
+    quad_step<M0, 0>(s, Up, dd, p, qmin, qmax);
+    quad_step<M0, 1>(s, Up, dd, p, qmin, qmax);
+    quad_step<M0, 2>(s, Up, dd, p, qmin, qmax);
+    quad_step<M0, 3>(s, Up, dd, p, qmin, qmax);
+    // every lane now holds the level, the error and the rounding residual of its own column 4 M0 + p
+    // the row's loss: the four columns' terms added in column order, in every lane of the quad alike (the
+    // row-per-lane kernel's and the oracle's order: ascending column)
+    {
+        const float t = (s.dv * s.dv) * dd[BS + 4 * M0 + p];
+        s.lsum = s.lsum + quad_bcast<0>(t);
+        s.lsum = s.lsum + quad_bcast<1>(t);
+        s.lsum = s.lsum + quad_bcast<2>(t);
+        s.lsum = s.lsum + quad_bcast<3>(t);
+    }
+    if (valid) {
+        const int c = 4 * M0 + p;
+        Qt[(size_t)(i1 + c) * R + row] = (int8_t)s.qv;
+        ErrT[(size_t)c * R + row] = s.ev;
+    }
+}
+
+template <int M0>
+__device__ __forceinline__ void quad_run(QuadState& s, const QuadScales& qs, const float* __restrict__ Up,
+                                         const float* __restrict__ dd, int p,
+                                         float qmin, float qmax, bool valid, int row, int R, int i1, int nm,
+                                         int8_t* __restrict__ Qt, float* __restrict__ ErrT) {
+    if constexpr (M0 < QM) {
+        if (M0 >= nm) return;       // ragged last block: cnt = 4 nm columns (wave-uniform)
+        quad_macro_step<M0>(s, qs, Up, dd, p, qmin, qmax, valid, row, R, i1, Qt, ErrT);
+        quad_run<M0 + 1>(s, qs, Up, dd, p, qmin, qmax, valid, row, R, i1, nm, Qt, ErrT);
+    }
+}
+
+__global__ __launch_bounds__(QTHREADS) void sweep_quad_kernel(float* __restrict__ W, int R, int K,
+                                                              const float* __restrict__ U,
+                                                              const float* __restrict__ scale_t,
+                                                              const float* __restrict__ zp_t,
+                                                              const int32_t* __restrict__ g_idx, int i1, int cnt,
+                                                              float qmin, float qmax, int8_t* __restrict__ Qt,
+                                                              float* __restrict__ ErrT, float* __restrict__ loss,
+                                                              int prio) {
+    qt_set_chain_prio(prio);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Up = sm;                      // [BS][QL][UP_P]
+    float* dd = sm + BS * UP_C;          // [BS] diag, [BS] 1 / diag^2
+    const int tid = threadIdx.x;
+    const int p = tid & (QL - 1);
+    const int row = blockIdx.x * QROWS + (tid >> 2);
+    const bool valid = row < R;
+    const int rowc = valid ? row : R - 1;
+    const int nm = cnt >> 2;             // cnt % 4 == 0 (K % 4 == 0)
+
+    {   // the U block, strictly above the diagonal, per (step, lane class); 16 independent float4 loads per thread
+        const float* ublk = U + (size_t)i1 * K + i1;
+        f32x4 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e4 = tid + QTHREADS * r;                 // float4 index in the 128 x 32 grid
+            const int i = e4 >> 5, j = (e4 & 31) * 4;
+            const int ic = i < cnt ? i : cnt - 1, jc = j < cnt ? j : cnt - 4;
+            v[r] = *(const f32x4*)(ublk + (size_t)ic * K + jc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e4 = tid + QTHREADS * r;
+            const int i = e4 >> 5, m = e4 & 31, j = m * 4;
+            const bool inside = i < cnt && j < cnt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Up[i * UP_C + q * UP_P + m] = (inside && j + q > i) ? v[r][q] : 0.0f;
+        }
+    }
+    if (tid < BS) {
+        const float d = (tid < cnt) ? U[(size_t)(i1 + tid) * K + (i1 + tid)] : 1.0f;
+        dd[tid] = d;
+        dd[BS + tid] = 1.0f / (d * d);   // only the loss uses it (tolerance 1e-6, not part of the bit-exact contract)
+    }
+    QuadState s;
+    {
+        const float* wrow = W + (size_t)rowc * K + i1 + p;
+#pragma unroll
+        for (int m = 0; m < QM; ++m) s.w[m] = m < nm ? wrow[4 * m] : 0.0f;
+    }
+    const QuadScales qs = {scale_t + rowc, zp_t + rowc, g_idx + i1 + p, R, nm};
+    quad_load_scales<0>(s, qs);
+    quad_load_scales<1>(s, qs);
+    quad_load_scales<2>(s, qs);
+    static_assert(QPF == 3, "the prologue loads the first QPF macro-steps' scales");
+    s.lsum = 0.0f;
+    s.qv = 0.0f;
+    s.ev = 0.0f;
+    s.dv = 0.0f;
+    __syncthreads();
+
+    quad_run<0>(s, qs, Up, dd, p, qmin, qmax, valid, row, R, i1, nm, Qt, ErrT);
+
+    if (valid) {   // dequantised values back to W (upstream: W[:, i1:i2] = Q1)
+        float* wrow = W + (size_t)row * K + i1 + p;
+#pragma unroll
+        for (int m = 0; m < QM; ++m)
+            if (m < nm) wrow[4 * m] = s.w[m];
+    }
+    if (valid && p == 0) loss[row] = loss[row] + s.lsum / 2.0f;
+}
+
 }  // namespace
 
 extern "C" size_t qt_gptq_sweep_workspace_bytes(int R, int K, int blocksize) {
@@ -218,6 +436,14 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
         return hipFuncSetAttribute((const void*)sweep_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)SWEEP_LDS);
     }));
+    static QtOncePerDevice lds_attr_q;
+    QT_HIP(lds_attr_q.run([&] {
+        return hipFuncSetAttribute((const void*)sweep_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)QUAD_LDS);
+    }));
+    // QT_SWEEP_BLOCK=row: the row-per-lane block kernel (the round-1/2 form; A/B and cross-check); default: four lanes per row
+    const char* blk_env = getenv("QT_SWEEP_BLOCK");
+    const bool quad = !(blk_env && blk_env[0] == 'r');
     QT_HIP(hipMemsetAsync(loss, 0, (size_t)R * 4, stream));
     // Lazy far update: the blocks of a batch update only the batch's own later columns right away
     // (k = 128, few columns); everything to the right of the batch gets the batch's chains in ONE
@@ -236,8 +462,12 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
             const int cnt = i2 - i1;
             float* err_blk = ErrT + (size_t)(i1 - b0) * R;
             qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
-            hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R,
-                               K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio);
+            if (quad)
+                hipLaunchKernelGGL(sweep_quad_kernel, dim3((R + QROWS - 1) / QROWS), dim3(QTHREADS), QUAD_LDS, stream, W,
+                                   R, K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio);
+            else
+                hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R,
+                                   K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio);
             qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
             QT_LAUNCH_CHECK();
             if (i2 < bend) {   // near update: the rest of this batch

@@ -95,3 +95,65 @@ def test_sgemm_sub_large_ragged_tiles_match_small_tile_path(ops, dev):
         for kk in range(k):
             acc = libm.fmaf(float(An[kk, m]), float(Bn[kk, n]), acc)
         assert np.float32(Cn[m, n]) - np.float32(acc) == out[m, n]
+
+
+@pytest.mark.parametrize("M,N,k,min_tiles", [
+    (128, 128, 64, 1),          # one tile, the shortest k the ring kernel takes (4 stages)
+    (256, 384, 128, 1),         # 6 tiles on 6 workgroups
+    (384, 128 * 9, 512, 1),     # 27 tiles
+    (4096, 128 * 40, 128, 1),   # 1280 tiles on 512 persistent workgroups: 2-3 tiles per workgroup, k = 128 (8 stages / tile)
+    (2048, 128 * 33, 64, 1),    # 528 tiles, 4 stages per tile: the C batches sit as close together as they can
+    (1024, 128 * 70, 1024, 1),  # 560 tiles, long k
+    (1024, 128 * 68, 256, 1),   # 544 tiles: 32 workgroups get two tiles, the rest one
+    (3072, 128 * 44, 128, 1),   # 1056 tiles
+])
+def test_ring_kernel_is_bit_identical_to_the_register_staged_kernel(ops, dev, M, N, k, min_tiles, monkeypatch):
+    """MODE_SUB through sgemm_ring_kernel (LDS-DMA ring, persistent over tiles, counted vmcnt) and through
+    sgemm_tn_kernel: per output element the same ascending-k fmaf chain from 0 and one subtraction, so every bit must
+    agree -- with C a column slice of a wider matrix (ldc > N), in place, as the sweep's far update calls it."""
+    g = torch.Generator(device=dev).manual_seed(M + N + k)
+    A = torch.randn((k, M), generator=g, device=dev)
+    Bw = torch.randn((k, N + 256), generator=g, device=dev)
+    B = Bw[:, 256:]
+    W0 = torch.randn((M, N + 256), generator=g, device=dev)
+    outs = {}
+    for ring in ("0", "1"):
+        monkeypatch.setenv("QT_SGEMM_RING", ring)
+        monkeypatch.setenv("QT_SGEMM_RING_MIN_TILES", str(min_tiles))
+        W = W0.clone()
+        C = W[:, 256:]
+        for _ in range(2):                       # twice in place: the second pass reads what the first wrote
+            ops.sgemm_tn(A, B, C, 0, out=C)
+        torch.cuda.synchronize()
+        outs[ring] = W
+    assert torch.equal(outs["0"], outs["1"])
+    assert torch.equal(outs["1"][:, :256], W0[:, :256])          # nothing outside the slice was touched
+    ref = W0[:, 256:].double() - 2 * (A.double().t() @ B.double())
+    torch.testing.assert_close(outs["1"][:, 256:].double(), ref, rtol=0, atol=4e-6 * k ** 0.5 * 16)
+
+
+def test_ring_kernel_chains_through_the_sweep(ops, dev, monkeypatch):
+    """The far update's chained form (four 128-deep chains per pass over W) runs on the ring kernel inside
+    qt_gptq_sweep: levels, losses and the updated W must equal the register-staged kernel's bit for bit."""
+    from tests.util import synth_activations, synth_weight, bits_to_bf16_tensor
+
+    K, R = 2048, 1024
+    X = bits_to_bf16_tensor(synth_activations(4 * K, K, seed=5), dev)
+    W = torch.from_numpy(synth_weight(R, K, seed=6)).to(dev).to(torch.bfloat16)
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    perm, inv = ops.argsort_desc(ops.hessian_diag(G, 8))
+    A, dead, _ = ops.hessian_prepare(G, 8, 0.01, perm)
+    U, info = ops.cholesky_inverse_upper(A)
+    sc, zp, sct, zpt = ops.group_minmax_qparams(W, 128, True, 4)
+    g_sweep = (torch.arange(K, device=dev, dtype=torch.int32) // 128)[perm.long()].contiguous()
+    outs = {}
+    for ring in ("0", "1"):
+        monkeypatch.setenv("QT_SGEMM_RING", ring)
+        monkeypatch.setenv("QT_SGEMM_RING_MIN_TILES", "1")
+        Wf = ops.weight_gather_f32(W, perm, dead)
+        Qt, loss = ops.gptq_sweep(Wf, U, sct, zpt, g_sweep, 128, 4)
+        torch.cuda.synchronize()
+        outs[ring] = (Qt, loss, Wf)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
