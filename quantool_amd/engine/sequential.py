@@ -62,6 +62,13 @@ def find_decoder_layers(model: nn.Module, sequential_targets=None) -> List[nn.Mo
     return list(max(outer, key=lambda nm: len(nm[1]))[1])
 
 
+#: What the calibration hooks need to know about the forward in flight: how many samples it carries and how many
+#: tokens each has.  Upstream feeds one sample per forward and counts one per forward that reaches a Linear
+#: (``num_added``); with several samples per forward a flattened ``[tokens, K]`` input -- an expert's routed rows --
+#: counts the samples those rows come from, which only the routing code knows (``_UnfusedExperts.forward``).
+_CALIB_CTX: Dict[str, Any] = {"samples": 1, "tokens_per_sample": None}
+
+
 class _UnfusedExperts(nn.Module):
     """Stand-in for a fused sparse-MoE expert bank (transformers >= 5: ``gate_up_proj [E, 2I, H]`` and
     ``down_proj [E, H, I]`` as 3-d parameters): every expert's two matrices become ``nn.Linear``
@@ -86,11 +93,16 @@ class _UnfusedExperts(nn.Module):
     def forward(self, hidden_states, top_k_index, top_k_weights):
         out = torch.zeros_like(hidden_states)
         mask = torch.nn.functional.one_hot(top_k_index, num_classes=self.num_experts).permute(2, 1, 0)
+        batch, per = _CALIB_CTX["samples"], _CALIB_CTX["tokens_per_sample"]
         for e in torch.greater(mask.sum(dim=(-1, -2)), 0).nonzero().flatten().tolist():
             pos, tok = torch.where(mask[e])
+            if batch > 1 and per:
+                # samples (of this forward) that routed at least one token here: what one forward per sample would count
+                _CALIB_CTX["samples"] = int(torch.unique(torch.div(tok, per, rounding_mode="floor")).numel())
             gate, up = self.experts[e].gate_up_proj(hidden_states[tok]).chunk(2, dim=-1)
             y = self.experts[e].down_proj(self.act_fn(gate) * up) * top_k_weights[tok, pos, None]
             out.index_add_(0, tok, y.to(out.dtype))
+        _CALIB_CTX["samples"] = batch
         return out
 
 
@@ -397,7 +409,7 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             # upstream counts one sample per forward of a batch-size-1 pipeline (num_added); with several samples
             # per forward a [B, T, K] input counts B, and a flattened [tokens, K] input (OPT's fc1, routed expert
             # tokens) counts the samples of the forward it came from
-            cur = {"samples": 1}
+            cur = _CALIB_CTX
 
             def add_hook(lead):
                 def fn(_m, a):
@@ -413,6 +425,7 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             for args, kwargs in cache:
                 h0 = args[0] if args else None
                 cur["samples"] = int(h0.shape[0]) if torch.is_tensor(h0) and h0.dim() >= 3 else 1
+                cur["tokens_per_sample"] = int(h0.shape[1]) if torch.is_tensor(h0) and h0.dim() >= 3 else None
                 layer(*args, **kwargs)
             for hk in hooks:
                 hk.remove()

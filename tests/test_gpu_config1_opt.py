@@ -34,7 +34,8 @@ def _opt(dev, layers=12):
     return OPTForCausalLM(cfg).to(torch.float16).to(dev).eval()
 
 
-def test_opt125m_shaped_fp16_through_the_gptq_plugin(dev, oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("calib_mode", ["merged", "per-sample"])
+def test_opt125m_shaped_fp16_through_the_gptq_plugin(dev, oracle, tmp_path, monkeypatch, calib_mode):
     import quantool_amd.methods  # noqa: F401
     from quantool_amd.core import QuantizerRegistry
     from quantool_amd.engine import sequential
@@ -49,9 +50,13 @@ def test_opt125m_shaped_fp16_through_the_gptq_plugin(dev, oracle, tmp_path, monk
     data = [{"input_ids": torch.randint(0, 2048, (96,), generator=g)} for _ in range(cfg["sample_size"])]
 
     monkeypatch.setattr(sequential, "DEBUG_KEEP", {})
-    # one sample per forward, as the per-sample hooks this test compares with: with several samples per forward
-    # (the default) the layer's own GEMMs / attention may round differently, which is not what is pinned here
-    monkeypatch.setenv("QT_CALIB_BATCH_TOKENS", "0")
+    # "merged" = the default mode (the 32 equal-length rows share one forward per layer; the plain hook the oracle is
+    # fed from sees the same stacked forward); "per-sample" = one sample per forward, the reference's calling pattern
+    batched = calib_mode == "merged"
+    if batched:
+        monkeypatch.delenv("QT_CALIB_BATCH_TOKENS", raising=False)
+    else:
+        monkeypatch.setenv("QT_CALIB_BATCH_TOKENS", "0")
     q = QuantizerRegistry.create(cfg["method"], model_id=cfg["model_id"], **qcfg)
     out = q.quantize(model=model, level=cfg["quant_level"], dataset=data, num_calibration_samples=cfg["sample_size"],
                      max_seq_length=128, shuffle_calibration_samples=False, **qcfg)
@@ -70,7 +75,7 @@ def test_opt125m_shaped_fp16_through_the_gptq_plugin(dev, oracle, tmp_path, monk
         k = by_members[frozenset(pre + s for s in members)]
         names = k["names"]                                          # the driver's own order inside the group
         sub = [n[len(pre):] for n in names]
-        acts = _hook_inputs(ref, r0.get_submodule(sub[0]), data, dev)
+        acts = _hook_inputs(ref, r0.get_submodule(sub[0]), data, dev, batched=batched)
         assert acts[0].dtype == torch.float16 and k["n"] == len(data)
         outs = _oracle_group(oracle, acts, [r0.get_submodule(s).weight.data for s in sub], k)
         assert np.array_equal(k["perm"].cpu().numpy(), outs[0]["perm"].astype(np.int32))
@@ -90,7 +95,7 @@ def test_opt125m_shaped_fp16_through_the_gptq_plugin(dev, oracle, tmp_path, monk
     pre1 = "model.decoder.layers.1."
     k1 = next(v for key, v in keep.items() if pre1 + "self_attn.q_proj" in v["names"])
     sub1 = [n[len(pre1):] for n in k1["names"]]
-    acts1 = _hook_inputs(ref, r1.get_submodule(sub1[0]), data, dev)
+    acts1 = _hook_inputs(ref, r1.get_submodule(sub1[0]), data, dev, batched=batched)
     outs1 = _oracle_group(oracle, acts1, [r1.get_submodule(s).weight.data for s in sub1], k1)
     for n, o in zip(k1["names"], outs1):
         np.testing.assert_array_equal(res[n].weight_packed.cpu().numpy(), oracle.pack_int4(o["q"]), err_msg=n)

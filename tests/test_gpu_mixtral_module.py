@@ -41,7 +41,8 @@ def test_unfused_experts_keep_the_function_and_the_storage(dev):
     assert len(linears) == 4 + 2 * 4 and uncovered_weight_fraction(layers[0], linears) < 0.02   # the router only
 
 
-def test_gptq_plugin_quantises_every_expert_on_its_routed_tokens(dev, oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("calib_mode", ["merged", "per-sample"])
+def test_gptq_plugin_quantises_every_expert_on_its_routed_tokens(dev, oracle, tmp_path, monkeypatch, calib_mode):
     import quantool_amd.methods  # noqa: F401
     from quantool_amd.core import QuantizerRegistry
     from quantool_amd.engine import sequential
@@ -55,9 +56,13 @@ def test_gptq_plugin_quantises_every_expert_on_its_routed_tokens(dev, oracle, tm
     g = torch.Generator().manual_seed(3)
     data = [{"input_ids": torch.randint(0, 512, (64,), generator=g)} for _ in range(8)]
     monkeypatch.setattr(sequential, "DEBUG_KEEP", {})
-    # one sample per forward, as the per-sample hooks this test compares with: with several samples per forward
-    # (the default) the layer's own GEMMs / attention may round differently, which is not what is pinned here
-    monkeypatch.setenv("QT_CALIB_BATCH_TOKENS", "0")
+    # "merged" = the default mode (the 8 equal-length rows share one forward per layer; the plain hook sees the same
+    # stacked forward, hence the same routing); "per-sample" = one sample per forward, the reference's calling pattern
+    batched = calib_mode == "merged"
+    if batched:
+        monkeypatch.delenv("QT_CALIB_BATCH_TOKENS", raising=False)
+    else:
+        monkeypatch.setenv("QT_CALIB_BATCH_TOKENS", "0")
     q = QuantizerRegistry.create("gptq", model_id="synthetic/tiny-mixtral")
     q.quantize(model=model, level="W4A16", dataset=data, num_calibration_samples=8, max_seq_length=64,
                shuffle_calibration_samples=False)
@@ -71,9 +76,13 @@ def test_gptq_plugin_quantises_every_expert_on_its_routed_tokens(dev, oracle, tm
             name = f"{pre}{e}.{which}"
             k = keep[name]
             mod = ref.model.layers[0].mlp.experts.experts[e].get_submodule(which)
-            acts = hook_inputs(ref, mod, data, dev)
+            acts = hook_inputs(ref, mod, data, dev, batched=batched)
             assert sum(a.shape[0] for a in acts) > 0
             counts.append(sum(a.shape[0] for a in acts))
+            # the Hessian's sample count is the number of SAMPLES that routed a token to this expert -- what one
+            # forward per sample counts (upstream's num_added), also when the samples shared a forward
+            per_sample = hook_inputs(ref, mod, data, dev) if batched else acts
+            assert k["n"] == sum(1 for a in per_sample if a.shape[0] > 0), name
             (o,) = oracle_group(oracle, acts, [mod.weight.data], k)
             np.testing.assert_array_equal(res[name].weight_packed.cpu().numpy(), oracle.pack_int4(o["q"]), err_msg=name)
     assert len(set(counts)) > 1                      # ragged: the experts saw different token counts

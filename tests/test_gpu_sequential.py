@@ -19,7 +19,8 @@ def _tiny_llama(dev):
     return LlamaForCausalLM(cfg).to(torch.bfloat16).to(dev)
 
 
-def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("calib_mode", ["merged", "per-sample"])
+def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch, calib_mode):
     import quantool_amd.methods  # noqa: F401
     from quantool_amd.core import QuantizerRegistry
     from safetensors.torch import load_file
@@ -35,9 +36,14 @@ def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
     from quantool_amd.engine import sequential
 
     monkeypatch.setattr(sequential, "DEBUG_KEEP", {})
-    # one sample per forward, as the per-sample hooks this test compares with: with several samples per forward
-    # (the default) the layer's own GEMMs / attention may round differently, which is not what is pinned here
-    monkeypatch.setenv("QT_CALIB_BATCH_TOKENS", "0")
+    # "merged" = the DEFAULT mode: equal-shape samples share a forward (here all 8 rows, one forward per layer), and
+    # the plain hook this test compares with sees the same stacked forward; "per-sample" = the reference's calling
+    # pattern (one sample per forward, QT_CALIB_BATCH_TOKENS=0) against per-sample hooks.  Both against the oracle.
+    batched = calib_mode == "merged"
+    if batched:
+        monkeypatch.delenv("QT_CALIB_BATCH_TOKENS", raising=False)
+    else:
+        monkeypatch.setenv("QT_CALIB_BATCH_TOKENS", "0")
     q = QuantizerRegistry.create("gptq", model_id="synthetic/tiny-llama")
     out = q.quantize(model=model, level="W4A16", dataset=data, num_calibration_samples=8, max_seq_length=64,
                      shuffle_calibration_samples=False)
@@ -60,7 +66,8 @@ def test_plugin_on_tiny_llama_sequential(dev, oracle, tmp_path, monkeypatch):
                     ["mlp.gate_proj", "mlp.up_proj"], ["mlp.down_proj"]):
         k = by_members[frozenset(pre + m for m in members)]
         sub = [n[len(pre):] for n in k["names"]]
-        acts = hook_inputs(ref, l0.get_submodule(sub[0]), data, dev)
+        acts = hook_inputs(ref, l0.get_submodule(sub[0]), data, dev, batched=batched)
+        assert k["n"] == len(data)                 # samples, not forwards
         outs = oracle_group(oracle, acts, [l0.get_submodule(m).weight.data for m in sub], k)
         for n, o in zip(k["names"], outs):
             np.testing.assert_array_equal(sd[f"{n}.weight_packed"].numpy(), oracle.pack_int4(o["q"]), err_msg=n)

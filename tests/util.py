@@ -29,13 +29,19 @@ def synth_weight(R: int, K: int, seed: int = 0, std: float = 0.02) -> np.ndarray
     return (rng.standard_normal((R, K)) * std).astype(np.float32)
 
 
-def hook_inputs(model, module, data, dev):
-    """What a plain forward-pre-hook on ``module`` sees over the calibration rows: list of [T, K]."""
+def hook_inputs(model, module, data, dev, batched=False):
+    """What a plain forward-pre-hook on ``module`` sees over the calibration rows: list of [T, K] (or [B * T, K]).
+    ``batched``: the (equal-length) rows go through the model in ONE forward, the way the sequential driver's
+    default mode stacks equal-shape samples (``engine.sequential.merge_cache``)."""
     got = []
     hk = module.register_forward_pre_hook(lambda m, a: got.append(a[0].detach().reshape(-1, a[0].shape[-1]).clone()))
     with torch.no_grad():
-        for row in data:
-            model(input_ids=row["input_ids"].reshape(1, -1).to(dev), use_cache=False)
+        if batched:
+            ids = torch.stack([row["input_ids"].reshape(-1) for row in data]).to(dev)
+            model(input_ids=ids, use_cache=False)
+        else:
+            for row in data:
+                model(input_ids=row["input_ids"].reshape(1, -1).to(dev), use_cache=False)
     hk.remove()
     return got
 

@@ -19,7 +19,12 @@ n_samples, seq = (int(x) for x in (sys.argv[4:6] if len(sys.argv) > 5 else (16, 
 g = torch.Generator().manual_seed(0)
 data = [{"input_ids": torch.randint(0, 1000, (seq,), generator=g)} for _ in range(n_samples)]
 probe = torch.randint(0, 1000, (1, 64), generator=g).to(dev)
+only = sys.argv[6].split(",") if len(sys.argv) > 6 else None      # e.g. "gptq" or "gptq,smoothquant"
+import logging
+logging.basicConfig(level=logging.WARNING)
 for method, level in (("gptq", "W4A16"), ("awq", "W4A16"), ("smoothquant", "W8A8"), ("awq", "W8A16")):
+    if only and method not in only:
+        continue
     cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=8,
                       num_key_value_heads=8, vocab_size=1000, max_position_embeddings=max(256, seq), tie_word_embeddings=False)
     torch.manual_seed(0)
