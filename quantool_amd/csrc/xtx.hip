@@ -27,6 +27,7 @@
 // walking the tokens together: a panel missed by one XCD's L2 is in the Infinity Cache for the rest.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <type_traits>
 #include <vector>
@@ -670,11 +671,52 @@ struct XtxPlan {
     size_t slab_bytes, tail_bytes, tab_bytes, prog_bytes;
 };
 
-// Lower-triangular tiles in locality order: bands of 16 tile rows, 16x16 macro blocks along a
-// band, 4 (rows) x 8 (cols) super-tiles inside a macro block, row-major inside a super-tile.  32
-// consecutive entries = one super-tile (12 distinct panels), 256 = one macro block (32 panels).
+// The round-1/2 order (QT_XTX_ORDER=0): bands of 16 tile rows, 16x16 macro blocks along a band, 4 (rows) x 8 (cols)
+// super-tiles inside a macro block, row-major inside a super-tile.  Off the diagonal 32 consecutive entries = one
+// super-tile (12 distinct panels) and 256 = one macro block (32 panels); the ragged diagonal macro blocks shift the
+// chunk boundaries, which is where the order above gains.
+// Lower-triangular tiles in locality order (the default since round 3; QT_XTX_ORDER=0 = the round-1/2 order below):
+// blocks of 8 consecutive panels, block rows walked in PAIRS (a, a + 1) column by column -- (a, b) and (a + 1, b)
+// share their column panels -- diagonal blocks as row-major triangles, off-diagonal blocks as 4 x 8 super-tiles.
+// What it buys: the 32 workgroups of an XCD take 32 consecutive entries, and a staged panel is an L2 hit for all
+// but the first of them that wants it.  Distinct panels per 32-entry chunk, summed over the table (tools/
+// xtx_tile_order_eval.py): K = 14336 (56 panels) 898 -> 701, i.e. best-case L2 hit 71.9 % -> 78.0 %; K = 28672:
+// 3491 -> 2659; per round of 256 entries (what decides the HBM share of the misses) unchanged, 248 -> 255.
+// Measured, same box, alternating processes: K = 14336 1337 -> 1362 TFLOP/s (+1.5...2 %), K = 4096 unchanged.
+static void xtx_tile_order_pairs(int nt, std::vector<int>& tab) {
+    const int m = 8, nb = (nt + m - 1) / m;
+    auto blk = [&](int a, int b) {
+        const int r0 = a * m, r1 = std::min(nt, r0 + m), c0 = b * m, c1 = std::min(nt, c0 + m);
+        if (a == b) {
+            for (int ti = r0; ti < r1; ++ti)
+                for (int tj = c0; tj <= ti; ++tj) tab.push_back((ti << 16) | tj);
+        } else {
+            for (int si = r0; si < r1; si += 4)
+                for (int ti = si; ti < std::min(si + 4, r1); ++ti)
+                    for (int tj = c0; tj < c1; ++tj) tab.push_back((ti << 16) | tj);
+        }
+    };
+    for (int a = 0; a < nb; a += 2) {
+        if (a + 1 < nb) {
+            for (int b = 0; b <= a + 1; ++b) {
+                if (b <= a) blk(a, b);
+                blk(a + 1, b);
+            }
+        } else {
+            for (int b = 0; b <= a; ++b) blk(a, b);
+        }
+    }
+}
+
 void xtx_tile_order(int nt, std::vector<int>& tab) {
     tab.clear();
+    {
+        const char* e = getenv("QT_XTX_ORDER");
+        if (!(e && atoi(e) == 0)) {
+            xtx_tile_order_pairs(nt, tab);
+            return;
+        }
+    }
     for (int bi = 0; bi < nt; bi += 16)
         for (int bj = 0; bj <= bi + 15 && bj < nt; bj += 16)
             for (int si = bi; si < bi + 16 && si < nt; si += 4)
