@@ -252,8 +252,7 @@ __device__ __forceinline__ void ring_wait_vmcnt() {
 }
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void sgemm_ring_kernel(RingArgs p) {
-    // the ring + 256 bytes per wave that swallow the C prefetch (below)
-    __shared__ __attribute__((aligned(16))) char ring[RS * RSTAGE_BYTES + 8 * 256];
+    __shared__ __attribute__((aligned(16))) char ring[RS * RSTAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave >> 1, wave_n = wave & 1;
@@ -351,23 +350,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cpre[j][r] - acc[j][r]), rs, cvoff_out + j * 128, soff, 0);
         }
     };
-    // C prefetch: ONE LDS-DMA dword per lane touches all 64 128-byte lines of the wave's 32 x 64 corner of a tile
-    // (lane -> row lane >> 1, half lane & 1), pulling them towards L2 a pair-step before the real loads; the data goes
-    // to a scratch corner of LDS nobody reads (no register is written, so nothing can be clobbered when it lands).
-    // vmcnt is in order: the real C loads have to be complete one pair-step after their issue or they hold up the
-    // panel DMA behind them -- from HBM that is too short, from L2 it is not.
-    const unsigned touch_voff = (unsigned)(((size_t)(lane >> 1) * (size_t)p.ldcin + (size_t)(lane & 1) * 32) * 4);
-    const unsigned touch_dst = __builtin_amdgcn_readfirstlane(ring_lds + RS * RSTAGE_BYTES + (unsigned)wave * 256u);
-    auto touch_c = [&](int m0, int n0) {
-        const float* base = p.Cin + (size_t)(m0 + wave_m * 32) * p.ldcin + n0 + wave_n * 64;
-        asm volatile(
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dword %0, %1"
-            :
-            : "v"(touch_voff), "s"(base), "s"(touch_dst)
-            : "memory");
-    };
     auto zero_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -388,8 +370,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // pair P - 1, whose reads every wave finished before arriving here.
     // vmcnt bookkeeping: vmcnt counts EVERY vector-memory operation of the wave in issue order (DMA, C loads, C
     // stores), so "pair P has landed" = "everything is done except what was issued after pair P's request", and the
-    // only such operations are the C batch of the END of pair-step P - 1: a tile's 32 stores (+ the next tile's one
-    // prefetch instruction) at the end of its last pair-step, or the 32 loads of a tile (not the first: prologue) at the end of its FIRST pair-step, into the
+    // only such operations are the C batch of the END of pair-step P - 1: a tile's 32 stores at the end of its last
+    // pair-step, or the 32 loads of a tile (not the first: prologue) at the end of its FIRST pair-step, into the
     // registers the previous tile's stores released one pair-step earlier.
     const int nchains = steps / fold_every;
     const int pairs_per_chain = fold_every / 2;
@@ -399,8 +381,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int ch = 0; ch < nchains; ++ch) {
             zero_acc();      // every chain starts from zero (its own accumulator live range: no copies at the loop edges)
             for (int ps = 0; ps < pairs_per_chain; ++ps, g += 2) {
-                if (batch_prev == 33) ring_wait_vmcnt<33>();
-                else if (batch_prev == 32) ring_wait_vmcnt<32>();
+                if (batch_prev) ring_wait_vmcnt<32>();
                 else ring_wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 if (g + 2 < total) {
@@ -440,11 +421,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         store_c(m0, n0);
         __builtin_amdgcn_sched_barrier(0);
         batch_prev = 32;
-        if (it + 1 < my_tiles) {
-            tile_origin(it + 1, m0, n0);
-            touch_c(m0, n0);          // one more operation in this batch
-            batch_prev = 33;
-        }
+        if (it + 1 < my_tiles) tile_origin(it + 1, m0, n0);
     }
 }
 
