@@ -92,11 +92,53 @@ __global__ __launch_bounds__(256) void argsort_rank_kernel(const float* __restri
     }
 }
 
+// The same rank counting spread over a 2-d grid: block (bx, by) counts, for its 256 values i, the j's of chunk by
+// (1024 values) that sort before them, and adds the partial count into rank[i] (integer atomics: exact, so the
+// result does not depend on the order of the adds).  K / 256 workgroups walking all K values one after the other
+// (the kernel above: 56 workgroups x 14336 dependent steps at K = 14336) become K^2 / 2^18 short ones.
+__global__ __launch_bounds__(256) void argsort_count_kernel(const float* __restrict__ d, int K,
+                                                            int32_t* __restrict__ rank) {
+    __shared__ float chunk[1024];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * 1024;
+    const float di = (i < K) ? d[i] : 0.0f;
+    const bool nan_i = di != di;
+    for (int e = threadIdx.x; e < 1024; e += 256) chunk[e] = (c0 + e < K) ? d[c0 + e] : -INFINITY;
+    __syncthreads();
+    const int lim = (K - c0 < 1024) ? K - c0 : 1024;
+    int cnt = 0;
+    for (int e = 0; e < lim; ++e) {
+        const float dj = chunk[e];
+        const bool nan_j = dj != dj;
+        const bool gt = nan_j ? !nan_i : (dj > di);
+        const bool eq = nan_j ? nan_i : (dj == di);
+        cnt += gt || (eq && (c0 + e) < i);
+    }
+    if (i < K && cnt) atomicAdd(rank + i, cnt);
+}
+
+__global__ __launch_bounds__(256) void argsort_scatter_kernel(const int32_t* __restrict__ rank, int K,
+                                                              int32_t* __restrict__ perm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) perm[rank[i]] = i;
+}
+
 }  // namespace
 
 extern "C" int qt_argsort_desc(const float* values, int K, int32_t* perm, int32_t* inv, qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(values && perm && K > 0, "qt_argsort_desc: bad arguments");
+    if (inv && K > 1024) {
+        // inv[i] = rank(i) is the accumulator of the 2-d count
+        QT_HIP(hipMemsetAsync(inv, 0, (size_t)K * sizeof(int32_t), stream));
+        hipLaunchKernelGGL(argsort_count_kernel, dim3((K + 255) / 256, (K + 1023) / 1024), dim3(256), 0, stream, values, K,
+                           inv);
+        QT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(argsort_scatter_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, (const int32_t*)inv, K,
+                           perm);
+        QT_LAUNCH_CHECK();
+        return QT_OK;
+    }
     hipLaunchKernelGGL(argsort_rank_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, values, K, perm, inv);
     QT_LAUNCH_CHECK();
     return QT_OK;

@@ -192,6 +192,28 @@ def test_argsort_desc_stable(ops, dev, K):
     np.testing.assert_array_equal(inv.cpu().numpy()[want], np.arange(K, dtype=np.int32))
 
 
+@pytest.mark.parametrize("K", [300, 5000])
+def test_argsort_desc_with_nan_and_inf_is_a_permutation(ops, dev, K):
+    """A non-finite activation can reach diag(H).  NaN orders as the largest value (as torch.argsort(descending=True)
+    places it), ties and NaNs keep ascending index: perm is a permutation for ANY input, on the one-pass kernel
+    (K <= 1024) and on the 2-d counting kernels (K > 1024) alike."""
+    g = torch.Generator(device=dev).manual_seed(K)
+    v = torch.randn(K, generator=g, device=dev)
+    v[3] = float("nan")
+    v[K - 2] = float("nan")
+    v[10] = float("inf")
+    v[11] = float("-inf")
+    v[20:30] = 0.5
+    perm, inv = ops.argsort_desc(v)
+    torch.cuda.synchronize()
+    p, iv = perm.cpu().numpy(), inv.cpu().numpy()
+    assert sorted(p.tolist()) == list(range(K))
+    np.testing.assert_array_equal(iv[p], np.arange(K, dtype=np.int32))
+    assert p[0] == 3 and p[1] == K - 2 and p[2] == 10 and p[-1] == 11
+    want = torch.argsort(v, descending=True, stable=True).cpu().numpy()
+    np.testing.assert_array_equal(p, want.astype(np.int32))
+
+
 def _check_factor(ops, oracle, dev, K):
     xb = synth_activations(4 * K, K, seed=K + 1)
     H = oracle.hessian_from_gram(oracle.gram_f64(xb), 8)
@@ -266,6 +288,25 @@ def test_cholesky_bf16x3_products_wide_dynamic_range(ops, oracle, dev, monkeypat
         assert np.all(np.abs(got - truth) <= 1e-4 * np.abs(truth) + 1e-6 * scale), name
     print(f"max error / max|U| vs fp64: f32 chain {errs['f32']:.2e}, bf16x3 products {errs['bf16x3']:.2e}")
     assert errs["bf16x3"] <= max(4 * errs["f32"], 5e-6)
+
+
+@pytest.mark.parametrize("K", [128, 384, 1024])
+def test_cholesky_ignores_the_strict_lower_triangle(ops, oracle, dev, K):
+    """`qt_hessian_prepare` writes the upper triangle of the flipped matrix only; whatever the allocation held
+    below it -- NaN and Inf included -- must not reach the factor (a masked MFMA lane multiplies by zero, and
+    0 * NaN is NaN: the rank-1 steps of potf2 mask both operands)."""
+    xb = synth_activations(4 * K, K, seed=K + 7)
+    H = oracle.hessian_from_gram(oracle.gram_f64(xb), 8)
+    Hd, _, _ = oracle.hessian_dead_and_damp(H, 0.01)
+    A0 = torch.from_numpy(np.ascontiguousarray(Hd[::-1, ::-1])).to(dev)
+    U0, info0 = ops.cholesky_inverse_upper(A0.clone())
+    poison = torch.full_like(A0, float("nan"))
+    poison[::3] = float("inf")
+    A1 = torch.triu(A0) + torch.tril(poison, -1)
+    U1, info1 = ops.cholesky_inverse_upper(A1)
+    torch.cuda.synchronize()
+    assert int(info0.item()) == 0 and int(info1.item()) == 0
+    assert torch.equal(U0, U1)
 
 
 def test_cholesky_reports_non_pd(ops, dev):
