@@ -56,6 +56,15 @@ size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K);
 int qt_xtx_accumulate(const void* X, int x_dtype, int64_t n_tokens, int K, int64_t ldx, float* G,
                       void* workspace, size_t workspace_bytes, qt_stream_t stream);
 
+/* The same accumulation for fp32 activations X [n_tokens, K] (an fp32 checkpoint: upstream's `inp.float()` is
+ * then an fp32 Gram product).  fp32-accurate on the bf16 MFMA: the tokens are split into three
+ * bf16 planes (residual <= 2^-27 |x|) and the six plane products of weight >= 2^-16 are summed in one fp32
+ * accumulator per lower-triangular tile, added into G.  K % 4 == 0, ldx % 4 == 0, X 16-byte aligned.
+ * Deterministic; 6x the MFMA work of the 16-bit path. */
+size_t qt_xtx_accumulate_f32_workspace_bytes(int64_t n_tokens, int K);
+int qt_xtx_accumulate_f32(const float* X, int64_t n_tokens, int K, int64_t ldx, float* G, void* workspace,
+                          size_t workspace_bytes, qt_stream_t stream);
+
 /* ---- a12/a13  activation statistics (AWQ / SmoothQuant hooks under base.py:161) ------------
  * abs_sum[K] += sum_t |x[t,k]|;  cmin[k] = min(cmin[k], min_t x);  cmax likewise.  Any of the
  * three outputs may be NULL.  The caller initialises abs_sum = 0, cmin = +inf, cmax = -inf.

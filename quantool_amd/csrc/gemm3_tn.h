@@ -31,7 +31,7 @@ struct G3Red {
     int pad;
 };
 
-enum { G3_SUB = 0, G3_SET = 1 };   // C -= product  /  C = product
+enum { G3_SUB = 0, G3_SET = 1, G3_ADD = 2 };   // C -= product  /  C = product  /  C += product
 
 struct G3Args {
     const unsigned short* Apl;   // plane 0 of the A operand, [rows][ld] bf16; plane q at + q * plane_stride

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "gemm3_tn.h"
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
                     if (gi < p.M && gj < p.N) {
                         float* dst = p.C + (size_t)gi * p.ldc + gj;
                         if (MODE == G3_SUB) *dst = *dst - acc[mi][ni][r];
+                        else if (MODE == G3_ADD) *dst = *dst + acc[mi][ni][r];
                         else *dst = acc[mi][ni][r];
                     }
                 }
@@ -245,11 +248,16 @@ __global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restri
                 f32x4 o = *(f32x4*)dst;
                 o -= s;
                 *(f32x4*)dst = o;
+            } else if (mode == G3_ADD) {
+                f32x4 o = *(f32x4*)dst;
+                o += s;
+                *(f32x4*)dst = o;
             } else {
                 *(f32x4*)dst = s;
             }
         } else {
-            for (int c = 0; c < 4 && gj + c < N; ++c) dst[c] = (mode == G3_SUB) ? dst[c] - s[c] : s[c];
+            for (int c = 0; c < 4 && gj + c < N; ++c)
+                dst[c] = (mode == G3_SUB) ? dst[c] - s[c] : (mode == G3_ADD) ? dst[c] + s[c] : s[c];
         }
     }
 }
@@ -311,6 +319,7 @@ int qt_gemm3_launch(const G3Args& a, hipStream_t stream) {
     p.slabs = a.slabs;
     p.items = a.items;
     if (a.mode == G3_SUB) hipLaunchKernelGGL((gemm3_kernel<G3_SUB>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
+    else if (a.mode == G3_ADD) hipLaunchKernelGGL((gemm3_kernel<G3_ADD>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((gemm3_kernel<G3_SET>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
     QT_LAUNCH_CHECK();
     if (a.n_red > 0) {
@@ -461,6 +470,106 @@ extern "C" int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int6
     g.red = (const G3Red*)(tab + qt_align_up(ib, 256));
     g.n_red = (int)red.size();
     return qt_gemm3_launch(g, stream);
+}
+
+// ---- a7 for fp32 activations (an fp32 checkpoint): G += X^T X with X fp32 [n_tokens, K] --------------------------
+// Upstream accumulates `inp.float()`: for an fp32 model that is an fp32 Gram product.  The bf16 Gram
+// kernel cannot take such activations without rounding them (8 significant bits); this entry point runs the product
+// on the same three-plane machinery the Cholesky chain uses: the token chunk is split into hi / mid / lo bf16 planes
+// (residual <= 2^-27 |x|) and every lower-triangular 256x256 tile accumulates its six plane products in one fp32 MFMA
+// accumulator, added into G from the epilogue -- fp32-accurate, 6 bf16-MFMA flops per fp32 flop.
+// Tokens are processed in chunks of XF_CHUNK rows (zero-padded to a multiple of 128) so the planes stay bounded.
+constexpr int XF_CHUNK = 8192;
+
+static int64_t xf_pitch(int K) { return (int64_t)qt_align_up((size_t)K, 256); }
+
+extern "C" size_t qt_xtx_accumulate_f32_workspace_bytes(int64_t n_tokens, int K) {
+    if (n_tokens <= 0 || K <= 0) return 0;
+    const int nt = (K + BT - 1) / BT;
+    return (size_t)3 * XF_CHUNK * xf_pitch(K) * 2 + qt_align_up((size_t)nt * (nt + 1) / 2 * sizeof(G3Item), 256) * 2 + 1024;
+}
+
+extern "C" int qt_xtx_accumulate_f32(const float* X, int64_t n_tokens, int K, int64_t ldx, float* G, void* workspace,
+                                     size_t workspace_bytes, qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(X && G && K > 0 && n_tokens >= 0 && ldx >= K, "qt_xtx_accumulate_f32: bad arguments");
+    QT_CHECK_ARG(K % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0,
+                 "qt_xtx_accumulate_f32: K, ldx must be multiples of 4 and X 16-byte aligned (K=%d)", K);
+    if (n_tokens == 0) return QT_OK;
+    const size_t need = qt_xtx_accumulate_f32_workspace_bytes(n_tokens, K);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_xtx_accumulate_f32: workspace %zu < required %zu", workspace_bytes, need);
+        return QT_ERR_WORKSPACE;
+    }
+    const int64_t ldp = xf_pitch(K);
+    const int64_t plane_stride = (int64_t)XF_CHUNK * ldp;
+    char* ws = (char*)qt_align_up((size_t)workspace, 256);
+    unsigned short* planes = (unsigned short*)ws;
+    const size_t planes_bytes = (size_t)3 * XF_CHUNK * ldp * 2;
+    char* tab = ws + planes_bytes;
+    const int nt = (K + BT - 1) / BT;
+    const size_t tab_bytes = qt_align_up((size_t)nt * (nt + 1) / 2 * sizeof(G3Item), 256);
+    // item tables (one per distinct chunk length: a full chunk, and the last one), pinned per (K, chunks)
+    static std::mutex m;
+    static std::map<std::pair<int, int>, G3Item*> tabs;
+    auto table = [&](int nch) -> const G3Item* {
+        std::lock_guard<std::mutex> lock(m);
+        auto key = std::make_pair(K, nch);
+        auto it = tabs.find(key);
+        if (it != tabs.end()) return it->second;
+        G3Item* pinned = nullptr;
+        if (hipHostMalloc((void**)&pinned, tab_bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        int n = 0;
+        for (int ti = 0; ti < nt; ++ti)
+            for (int tj = 0; tj <= ti; ++tj) pinned[n++] = {(ti << 16) | tj, 0, nch, -1};
+        tabs[key] = pinned;
+        return pinned;
+    };
+    // columns K..ldp of the planes are never written by the split (edge tiles read them): zero them once per call
+    if (ldp != K) QT_HIP(hipMemsetAsync(planes, 0, planes_bytes, stream));
+    int slot = 0;
+    for (int64_t t0 = 0; t0 < n_tokens; t0 += XF_CHUNK) {
+        const int rows = (int)std::min<int64_t>(XF_CHUNK, n_tokens - t0);
+        const int rows_pad = (rows + 127) / 128 * 128;            // items are whole chunks of 64 rows, at least two
+        if (rows_pad != rows) {
+            // the rows behind a ragged last chunk may hold an earlier chunk's planes: zero them
+            for (int q = 0; q < 3; ++q)
+                QT_HIP(hipMemsetAsync(planes + q * plane_stride + (size_t)rows * ldp, 0, (size_t)(rows_pad - rows) * ldp * 2,
+                                      stream));
+        }
+        int rc = qt_split3_launch(X + (size_t)t0 * ldx, ldx, rows, K, planes, ldp, plane_stride, 0, 0, 0, stream);
+        if (rc) return rc;
+        const int nch = rows_pad / CH_ROWS;
+        const G3Item* host_tab = table(nch);
+        if (!host_tab) {
+            qt_set_error("qt_xtx_accumulate_f32: hipHostMalloc failed");
+            return QT_ERR_HIP;
+        }
+        char* dev_tab = tab + (size_t)(slot & 1) * tab_bytes;     // two slots: a full-chunk and a last-chunk table
+        ++slot;
+        QT_HIP(hipMemcpyAsync(dev_tab, host_tab, (size_t)nt * (nt + 1) / 2 * sizeof(G3Item), hipMemcpyHostToDevice, stream));
+        G3Args g;
+        g.Apl = planes;
+        g.Bpl = planes;
+        g.plane_stride = plane_stride;
+        g.ld = ldp;
+        g.rowA0 = g.rowB0 = 0;
+        g.colA0 = g.colB0 = 0;
+        g.colmax = (int)ldp;
+        g.M = K;
+        g.N = K;
+        g.C = G;
+        g.ldc = K;
+        g.mode = G3_ADD;
+        g.slabs = nullptr;
+        g.items = (const G3Item*)dev_tab;
+        g.n_items = nt * (nt + 1) / 2;
+        g.red = nullptr;
+        g.n_red = 0;
+        rc = qt_gemm3_launch(g, stream);
+        if (rc) return rc;
+    }
+    return QT_OK;
 }
 
 // Host-only self-check of the block-row planner (no GPU needed; tests/test_gemm3_plan.py): every k chunk of

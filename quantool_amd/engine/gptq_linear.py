@@ -66,12 +66,23 @@ class HessianAccumulator:
         if t == 0:
             return
         if X2.dtype not in (torch.bfloat16, torch.float16):
-            ops.wide_activation_policy(X2.dtype)      # fp32 activations: rounded to bf16, loudly (or refused)
+            mode = ops.wide_gram_mode()
+            if mode == "exact":
+                # an fp32 checkpoint: upstream accumulates inp.float(), i.e. an fp32 Gram product -- staged and
+                # accumulated in fp32 through the three-plane product (ops.xtx_accumulate_f32)
+                if X2.dtype != torch.float32:
+                    X2 = X2.float()
+                if self.dtype is None:
+                    self.dtype = torch.float32
+            else:
+                ops.wide_activation_policy(X2.dtype)      # rounded to bf16, loudly (or refused)
         if self.dtype is None:
             # the checkpoint's own dtype (the reference injects none, base.py:222-241); see ops.as_act16
             self.dtype = X2.dtype if X2.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+        if self.dtype == torch.float32 and self.stage_tokens > 0 and self._stage is None:
+            self.stage_tokens = max(128, self.stage_tokens // 2 // 128 * 128)     # same bytes of staging at 4 B / element
         if self.stage_tokens <= 0 or t >= min(self.DIRECT_TOKENS, self.stage_tokens):
-            ops.xtx_accumulate(X2 if X2.dtype == self.dtype else X2.to(self.dtype), self._G)
+            self._gram(X2 if X2.dtype == self.dtype else X2.to(self.dtype))
             return
         if self._stage is None:
             self._stage = torch.empty((self.stage_tokens, self.K), dtype=self.dtype, device=self._G.device)
@@ -80,9 +91,15 @@ class HessianAccumulator:
         self._stage[self._fill:self._fill + t].copy_(X2)     # also the dtype conversion, if any
         self._fill += t
 
+    def _gram(self, rows: torch.Tensor) -> None:
+        if rows.dtype == torch.float32:
+            ops.xtx_accumulate_f32(rows, self._G)
+        else:
+            ops.xtx_accumulate(rows, self._G)
+
     def flush(self) -> None:
         if self._fill:
-            ops.xtx_accumulate(self._stage[:self._fill], self._G)
+            self._gram(self._stage[:self._fill])
             self._fill = 0
 
     def release_stage(self) -> None:

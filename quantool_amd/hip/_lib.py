@@ -26,6 +26,8 @@ SIGNATURES = {
     "qt_last_error": (c_char_p, []),
     "qt_xtx_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "qt_xtx_accumulate": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "qt_xtx_accumulate_f32_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "qt_xtx_accumulate_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "qt_act_stats_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "qt_act_stats_accumulate": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_size_t, c_void_p]),

@@ -52,16 +52,25 @@ def as_act16(X: torch.Tensor) -> torch.Tensor:
     """Activations as the kernels take them: the model's own 16-bit dtype, untouched.  Upstream
     accumulates ``inp.float()``; bf16 and fp16 widen exactly, so nothing is lost.
 
-    fp32 activations (an fp32 checkpoint) are the one case that is NARROWER than the reference: they are
-    rounded to bf16 for the Gram / statistics passes (range over mantissa: an fp16 cast could overflow on
-    outlier channels).  That downgrade is never silent: it is logged once per process, and with
-    ``QT_FP32_ACTIVATIONS=error`` it is refused (``ValueError``) so that a pipeline which must match an
-    fp32 reference run bit for bit cannot pick it up unnoticed.  Loading the model with ``precision="bf16"``
-    (upstream's own default for GPU runs) avoids the case altogether."""
+    fp32 activations (an fp32 checkpoint): the Gram accumulation has its own fp32-accurate path
+    (``xtx_accumulate_f32`` / ``HessianAccumulator``) and does not come here.  The STATISTICS passes (AWQ's mean |x|,
+    SmoothQuant's channel min / max) take 16-bit rows, so for them -- and for the Gram pass under
+    ``QT_FP32_ACTIVATIONS=bf16`` -- fp32 activations are rounded to bf16 (range over mantissa: an fp16 cast could
+    overflow on outlier channels).  That downgrade is never silent: it is logged once per process, and with
+    ``QT_FP32_ACTIVATIONS=error`` it is refused (``ValueError``)."""
     if X.dtype in (torch.bfloat16, torch.float16):
         return X
     wide_activation_policy(X.dtype)
     return X.to(torch.bfloat16)
+
+
+def wide_gram_mode() -> str:
+    """How the Gram accumulation takes fp32 activations: "exact" (default: the three-plane fp32-accurate product,
+    6x the MFMA work), "bf16" (round them, logged once) or "error" -- ``QT_FP32_ACTIVATIONS``."""
+    mode = os.environ.get("QT_FP32_ACTIVATIONS", "exact").lower()
+    if mode not in ("exact", "bf16", "warn", "error"):
+        raise ValueError(f"QT_FP32_ACTIVATIONS={mode!r}: expected exact, bf16 or error")
+    return "bf16" if mode == "warn" else mode
 
 
 def wide_activation_policy(dtype) -> None:
@@ -69,7 +78,7 @@ def wide_activation_policy(dtype) -> None:
     if dtype not in (torch.float32, torch.float64):
         raise TypeError(f"calibration activations must be floating point, got {dtype}")
     global _FP32_ACT_WARNED
-    policy = os.environ.get("QT_FP32_ACTIVATIONS", "warn").lower()
+    policy = os.environ.get("QT_FP32_ACTIVATIONS", "exact").lower()
     if policy == "error":
         raise ValueError(f"{dtype} calibration activations: this backend accumulates X^T X from 16-bit activations; "
                          "load the model in bf16 / fp16 (oneshot(precision=...)) or unset QT_FP32_ACTIVATIONS=error to "
@@ -128,6 +137,31 @@ def xtx_accumulate(X: torch.Tensor, G: torch.Tensor) -> None:
     ws = workspace(nbytes, X.device, "xtx")
     check("qt_xtx_accumulate", lib.qt_xtx_accumulate(X2.data_ptr(), xdt, n, K, ldx, G.data_ptr(), ws.data_ptr(),
                                                      ws.numel(), _stream()))
+
+
+def xtx_accumulate_f32(X: torch.Tensor, G: torch.Tensor) -> None:
+    """G[K,K] fp32 (lower triangle) += X^T X for fp32 X[..., K]: the fp32-accurate three-plane product (an fp32
+    checkpoint's activations, which upstream accumulates as `inp.float()`)."""
+    lib = load()
+    _req(X, torch.float32, "X")
+    _req(G, torch.float32, "G", 2)
+    K = G.shape[0]
+    if G.shape[1] != K or not G.is_contiguous():
+        raise ValueError("G must be contiguous [K, K]")
+    if X.shape[-1] != K:
+        raise ValueError(f"X last dim {X.shape[-1]} != K {K}")
+    if K % 4:
+        raise ValueError(f"fp32 activations need in_features % 4 == 0 (K = {K})")
+    X2 = X.reshape(-1, K)
+    if X2.stride(1) != 1 or X2.stride(0) % 4 or X2.data_ptr() % 16:
+        X2 = X2.contiguous()
+    n = X2.shape[0]
+    if n == 0:
+        return
+    ldx = X2.stride(0) if n > 1 else K
+    ws = workspace(lib.qt_xtx_accumulate_f32_workspace_bytes(n, K), X.device, "xtx_f32")
+    check("qt_xtx_accumulate_f32", lib.qt_xtx_accumulate_f32(X2.data_ptr(), n, K, ldx, G.data_ptr(), ws.data_ptr(),
+                                                             ws.numel(), _stream()))
 
 
 # ---- a12 / a13 ----------------------------------------------------------------------------

@@ -1,6 +1,7 @@
-"""fp32 calibration activations (an fp32 checkpoint) are the one input the backend takes narrower than
-the reference, which accumulates ``inp.float()``: they are rounded to bf16 -- loudly, and
-refusably.  Host logic only (the policy check runs before any device call)."""
+"""fp32 calibration activations (an fp32 checkpoint; the reference accumulates ``inp.float()``): the Gram
+accumulation takes them through its fp32-accurate three-plane product by default (GPU test:
+tests/test_gpu_fp32_activations.py); the statistics passes -- and the Gram pass under QT_FP32_ACTIVATIONS=bf16 --
+round them to bf16, loudly and refusably.  Host logic only (the policy checks run before any device call)."""
 import logging
 
 import pytest
@@ -39,3 +40,14 @@ def test_fp32_activations_can_be_refused(monkeypatch):
 def test_integer_activations_are_a_type_error():
     with pytest.raises(TypeError):
         ops.as_act16(torch.ones(4, 8, dtype=torch.int32))
+
+
+def test_gram_mode_knob(monkeypatch):
+    monkeypatch.delenv("QT_FP32_ACTIVATIONS", raising=False)
+    assert ops.wide_gram_mode() == "exact"
+    for v, want in (("bf16", "bf16"), ("warn", "bf16"), ("error", "error"), ("EXACT", "exact")):
+        monkeypatch.setenv("QT_FP32_ACTIVATIONS", v)
+        assert ops.wide_gram_mode() == want
+    monkeypatch.setenv("QT_FP32_ACTIVATIONS", "fp8")
+    with pytest.raises(ValueError):
+        ops.wide_gram_mode()

@@ -95,10 +95,16 @@ def test_awq_and_smoothquant_helpers_take_fp16(ops, oracle, dev):
     np.testing.assert_array_equal(scale.cpu().numpy(), o_s)
 
 
-def test_fp32_activations_are_narrowed_to_bf16_explicitly(dev):
-    """The one dtype this backend does narrow (documented in DESIGN.md section 2)."""
+def test_fp32_activations_keep_their_precision_by_default(dev, monkeypatch):
+    """fp32 batches are staged and accumulated in fp32 (the three-plane Gram product, tests/test_gpu_fp32_activations.py);
+    QT_FP32_ACTIVATIONS=bf16 is the explicit downgrade."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator
 
+    monkeypatch.delenv("QT_FP32_ACTIVATIONS", raising=False)
+    acc = HessianAccumulator(64, dev)
+    acc.add(torch.randn(2, 16, 64, device=dev))
+    assert acc.dtype == torch.float32 and acc.n == 2
+    monkeypatch.setenv("QT_FP32_ACTIVATIONS", "bf16")
     acc = HessianAccumulator(64, dev)
     acc.add(torch.randn(2, 16, 64, device=dev))
     assert acc.dtype == torch.bfloat16 and acc.n == 2
