@@ -11,12 +11,12 @@ vals = defaultdict(list)
 dur = []
 for f in glob.glob(f"{out}/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "xtx_" not in row.get("Kernel_Name", "") or "reduce" in row.get("Kernel_Name", ""):
+        if "xtx" not in row.get("Kernel_Name", "") or "reduce" in row.get("Kernel_Name", ""):
             continue
         vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for f in glob.glob(f"{out}/**/*kernel_trace.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "xtx_" in row.get("Kernel_Name", "") and "reduce" not in row["Kernel_Name"]:
+        if "xtx" in row.get("Kernel_Name", "") and "reduce" not in row["Kernel_Name"]:
             dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
 # the first launch of xtx_only.py is a short warm-up on 8192 tokens: keep the long ones
 full = [d for d in dur if d > 0.5 * max(dur)] if dur else []

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_xtx_pmc_traffic.json from the PMC passes of tools/xtx_pmc.sh at K = 4096 and K = 14336
+"""profiles/rNN_xtx_pmc_traffic.json from the PMC passes of tools/xtx_pmc.sh at K = 4096 and K = 14336
 (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, per xtx_kernel launch; the bench's `roofline.traffic`
 is the average over the 4 Gram launches of a step: 3 x K=4096 + 1 x K=14336)."""
 import csv
@@ -13,7 +13,7 @@ for K, d in ((4096, sys.argv[1]), (14336, sys.argv[2])):
     vals = {}
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "xtx_kernel" in row["Kernel_Name"]:
+            if "xtx" in row["Kernel_Name"] and "reduce" not in row["Kernel_Name"]:   # xtx_kernel / xtx16_kernel
                 vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     per = {}
     for k, v in vals.items():
