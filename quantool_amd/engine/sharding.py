@@ -111,23 +111,26 @@ def allreduce_gram(G: torch.Tensor, n_samples: int, group=None):
     ranks, every rank accumulates its own partial Gram sum and the partials are summed once before
     the factorisation.  Only the lower triangle of G is valid (the Gram kernel computes lower
     256 x 256 tiles), so only its 256-row bands travel: packed into one flat buffer, ONE all-reduce
-    of ~K^2/2 fp32 (34 MB at K = 4096, 415 MB at K = 14336 -- half the full matrix), unpacked in place.
+    of ~K^2/2 fp32 (34 MB at K = 4096, 415 MB at K = 14336 -- half the full matrix) that also carries the
+    sample count, unpacked in place.
     Returns the global sample count.  The sum order of an all-reduce is fixed by the ring, not by
     this code: bit-identical results across world sizes are not guaranteed (H within 1e-5 is)."""
     import torch.distributed as dist
 
     K = G.shape[0]
     bands = list(_lower_block_rows(K))
-    flat = torch.cat([G[rows, :cols].reshape(-1) for rows, cols in bands])
+    if not 0 <= int(n_samples) < (1 << 24) // max(1, dist.get_world_size(group)):
+        raise ValueError(f"sample count {n_samples} does not travel exactly as fp32 next to the Gram bands")
+    # the sample count rides at the end of the same buffer (integers < 2^24 add exactly in fp32)
+    count = torch.tensor([float(int(n_samples))], dtype=G.dtype, device=G.device)
+    flat = torch.cat([G[rows, :cols].reshape(-1) for rows, cols in bands] + [count])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for rows, cols in bands:
         cnt = (rows.stop - rows.start) * cols
         G[rows, :cols] = flat[off:off + cnt].view(rows.stop - rows.start, cols)
         off += cnt
-    n = torch.tensor([int(n_samples)], dtype=torch.int64, device=G.device)
-    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
-    return int(n.item())
+    return int(round(float(flat[off].item())))
 
 
 # ---- partitioning B (SURVEY 8e): one Linear group spread over the ranks ------------------------
@@ -215,27 +218,27 @@ class GatheredResult:
         return self._w_dq.to(dtype)
 
 
-def _all_gather_rows(mine_t: Optional[torch.Tensor], slices, rank: int, dev, group):
-    """All-gather a row-split tensor (some ranks may hold no rows).  Returns None when no rank has it."""
-    import torch.distributed as dist
+def _row_split_schema(weights, qargs, K: int, with_dequantized: bool):
+    """Per weight, the row-split outputs every rank holds for its rows: [(key, columns, dtype)].  A function of
+    the quantisation arguments and the weight's dtype alone, so that every rank -- also one that swept no
+    rows of this weight -- lays out the gather buffer the same way without asking the others."""
+    gs = qargs.kernel_group_size
+    G = 1 if gs <= 0 else K // gs
+    out = []
+    for w in weights:
+        cols = [("weight_packed", (K + 7) // 8, torch.int32)] if int(qargs.num_bits) == 4 else \
+               [("weight_q", K, torch.int8)]
+        cols.append(("weight_scale", G, w.dtype if w.dtype in (torch.bfloat16, torch.float16) else torch.float32))
+        if not qargs.symmetric:
+            cols.append(("weight_zero_point", G, torch.int8))
+        if with_dequantized:
+            cols.append(("@dequantized", K, w.dtype))
+        out.append(cols)
+    return out
 
-    world = len(slices)
-    metas = [None] * world
-    dist.all_gather_object(metas, None if mine_t is None else
-                           (int(mine_t.shape[1]), str(mine_t.dtype).replace("torch.", "")), group=group)
-    ref = next((m for m in metas if m is not None), None)
-    if ref is None:
-        return None                                    # e.g. symmetric: no zero point anywhere
-    b, e = slices[rank]
-    tallest = max(eb - bb for bb, eb in slices)
-    # all_gather wants equal shapes: every rank sends `tallest` rows, the tail is padding
-    send = torch.zeros((tallest, ref[0]), dtype=getattr(torch, ref[1]), device=dev)
-    if mine_t is not None:
-        send[:e - b] = mine_t
-    send = _comm(send, group)
-    bufs = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(bufs, send, group=group)
-    return torch.cat([buf[:eb - bb] for buf, (bb, eb) in zip(bufs, slices)], 0).to(dev)
+
+def _pad16(n: int) -> int:
+    return (n + 15) // 16 * 16
 
 
 def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, group=None, block_size: int = 128,
@@ -243,7 +246,9 @@ def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, grou
     """Steps 3-4 of partitioning B on an accumulator that already holds the GLOBAL Gram sum: every rank
     factorises the same Hessian (replicated: 2/3 K^3 flop is cheaper than moving the K^2 factor), sweeps
     only its contiguous slice of every weight's rows (rows are independent given U), and the packed
-    rows, scales (and, for the sequential driver's write-back, the dequantised rows) are all-gathered."""
+    rows, scales (and, for the sequential driver's write-back, the dequantised rows) of ALL the group's
+    weights travel in ONE all-gather of a byte buffer whose layout every rank derives from the arguments
+    (no per-tensor collectives, no object collectives: one message per peer per Linear group)."""
     import torch.distributed as dist
 
     from .gptq_linear import gptq_quantize_shared
@@ -251,34 +256,76 @@ def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, grou
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     K = int(weights[0].shape[1])
     dev = weights[0].device
-    mine = [row_slices(int(w.shape[0]), world)[rank] for w in weights]
+    slices = [row_slices(int(w.shape[0]), world) for w in weights]
+    mine = [sl[rank] for sl in slices]
     local = [w[b:e] for w, (b, e) in zip(weights, mine) if e > b]
     res = iter(gptq_quantize_shared(local, acc, qargs, block_size=block_size, dampening_frac=dampening_frac)
                if local else [])
-    out = []
-    for w, (b, e) in zip(weights, mine):
+    schema = _row_split_schema(weights, qargs, K, with_dequantized)
+    with_gidx = str(qargs.actorder).lower() == "group"
+
+    def rank_bytes(r: int) -> int:
+        n = _pad16(4 * K) if with_gidx else 0
+        for sl, cols in zip(slices, schema):
+            rows = sl[r][1] - sl[r][0]
+            n += sum(_pad16(rows * c * torch.empty(0, dtype=dt).element_size()) for _, c, dt in cols)
+        return n
+
+    width = max(rank_bytes(r) for r in range(world))
+    send = torch.zeros(width, dtype=torch.uint8, device=dev)
+    off = 0
+    g_idx_local = None
+    results = []
+    for (b, e), cols in zip(mine, schema):
         r = next(res) if e > b else None
+        results.append(r)
+        for key, c, dt in cols:
+            nbytes = (e - b) * c * torch.empty(0, dtype=dt).element_size()
+            if r is not None:
+                t = r.dequantized(dt) if key == "@dequantized" else getattr(r, key)
+                if t is None or tuple(t.shape) != (e - b, c) or t.dtype != dt:
+                    raise RuntimeError(f"row-split gather: {key} is {None if t is None else (tuple(t.shape), t.dtype)}, "
+                                       f"the layout every rank assumes says {((e - b, c), dt)}")
+                send[off:off + nbytes] = t.contiguous().reshape(-1).view(torch.uint8)
+            off += _pad16(nbytes)
+        if r is not None and with_gidx and g_idx_local is None:
+            g_idx_local = r.weight_g_idx
+    if with_gidx:
+        if g_idx_local is not None:
+            send[off:off + 4 * K] = g_idx_local.to(torch.int32).contiguous().view(torch.uint8)
+        off += _pad16(4 * K)
+    send = _comm(send, group)
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(bufs, send, group=group)
+    bufs = [buf.to(dev) for buf in bufs]
+
+    offs = [0] * world
+    out = []
+    for w, sl, cols in zip(weights, slices, schema):
         R = int(w.shape[0])
-        slices = row_slices(R, world)
-        parts = {}
-        for key in ("weight_packed", "weight_q", "weight_scale", "weight_zero_point"):
-            got = _all_gather_rows(getattr(r, key, None) if r is not None else None, slices, rank, dev, group)
-            if got is not None:
-                parts[key] = got
-        w_dq = None
-        if with_dequantized:
-            w_dq = _all_gather_rows(r.dequantized(w.dtype) if r is not None else None, slices, rank, dev, group)
-        if str(qargs.actorder).lower() == "group":
-            # the same on every rank that swept rows; ranks without rows get it from the first that did
-            g_idx = r.weight_g_idx if r is not None else None
-            if any(eb == bb for bb, eb in slices):
-                holder = [None if g_idx is None else g_idx.cpu()]
-                src = next(k for k, (bb, eb) in enumerate(slices) if eb > bb)
-                dist.broadcast_object_list(holder, src=src, group=group)
-                g_idx = holder[0].to(dev)
-            parts["weight_g_idx"] = g_idx
+        parts, w_dq = {}, None
+        for key, c, dt in cols:
+            es = torch.empty(0, dtype=dt).element_size()
+            pieces = []
+            for r in range(world):
+                rows = sl[r][1] - sl[r][0]
+                nbytes = rows * c * es
+                if rows:
+                    pieces.append(bufs[r][offs[r]:offs[r] + nbytes].view(dt).reshape(rows, c))
+                offs[r] += _pad16(nbytes)
+            full = torch.cat(pieces, 0)
+            if key == "@dequantized":
+                w_dq = full
+            else:
+                parts[key] = full
         parts["weight_shape"] = torch.tensor([R, K], dtype=torch.int64)
         out.append(GatheredResult(parts, w_dq))
+    if with_gidx:
+        # the same on every rank that swept rows (one Hessian, one permutation): taken from the first that did
+        src = next(r for r in range(world) if any(sl[r][1] > sl[r][0] for sl in slices))
+        g_idx = bufs[src][offs[src]:offs[src] + 4 * K].view(torch.int32).clone()
+        for o in out:
+            o.weight_g_idx = g_idx
     return out
 
 

@@ -106,10 +106,11 @@ def test_plan_groups_splits_what_exceeds_a_fair_share():
     assert plan_groups(big, 2)[0] == ("B", -1) and plan_groups(big, 8)[0] == ("B", -1)
 
 
-def _row_split_worker(rank, world, port, q):
+def _row_split_worker(rank, world, port, q, variant):
     """Control flow of partitioning B's gather step on CPU tensors: the per-rank sweep is replaced by a
     stand-in (the real one needs a GPU); what is checked is who sweeps which rows and how the rows of
-    every tensor come back together, including a rank that owns no row of a weight."""
+    every tensor come back together -- in ONE collective per call -- including a rank that owns no row
+    of a weight, an asymmetric scheme's zero points, 8-bit levels and actorder="group"'s g_idx."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -117,41 +118,80 @@ def _row_split_worker(rank, world, port, q):
         import types
 
         import quantool_amd.engine.gptq_linear as gl
-        from quantool_amd.engine.sharding import gptq_quantize_row_split
+        import quantool_amd.engine.sharding as sh
 
+        bits, symmetric, actorder, wdt = variant
+        K, gs = 16, 8
         seen_rows = []
+        perm = torch.arange(K, dtype=torch.int32).flip(0) // gs
+
+        def levels(w):
+            return (w.float() * 10).round().clamp(-100, 100).to(torch.int8)
 
         def fake_shared(weights, acc, qargs, **kw):
             out = []
             for w in weights:
                 seen_rows.append(int(w.shape[0]))
                 out.append(types.SimpleNamespace(
-                    weight_packed=(w[:, :4] * 1000).to(torch.int32), weight_q=None,
-                    weight_scale=w[:, :2].to(torch.bfloat16), weight_zero_point=None, weight_g_idx=None,
+                    weight_packed=(w[:, :2].float() * 1000).to(torch.int32) if bits == 4 else None,
+                    weight_q=None if bits == 4 else levels(w),
+                    weight_scale=w[:, :2].clone(),
+                    weight_zero_point=None if symmetric else levels(w)[:, 3:5].contiguous(),
+                    weight_g_idx=perm.clone() if actorder == "group" else None,
                     dequantized=lambda dtype, w=w: (w * 2).to(dtype)))
             return out
 
+        calls = {"all_gather": 0, "other": 0}
+        real_all_gather = dist.all_gather
+
+        def counting_all_gather(*a, **kw):
+            calls["all_gather"] += 1
+            return real_all_gather(*a, **kw)
+
+        def refuse(*a, **kw):
+            calls["other"] += 1
+            raise AssertionError("row-split gather issued a second kind of collective")
+
         gl.gptq_quantize_shared = fake_shared
+        dist.all_gather = counting_all_gather
+        dist.all_gather_object = dist.broadcast_object_list = dist.broadcast = refuse
         g = torch.Generator().manual_seed(5)
-        Ws = [torch.randn(r, 8, generator=g) for r in (7, 1, 4)]          # 1 row: rank 1 owns nothing of it
-        qa = types.SimpleNamespace(actorder="static")
-        res = gptq_quantize_row_split(Ws, None, qa, with_dequantized=True)
+        Ws = [torch.randn(r, K, generator=g).to(wdt) for r in (7, 1, 4)]   # 1 row: rank 1 owns nothing of it
+        qa = types.SimpleNamespace(actorder=actorder, num_bits=bits, symmetric=symmetric, kernel_group_size=gs)
+        res = sh.gptq_quantize_row_split(Ws, None, qa, with_dequantized=True)
         ok = seen_rows == ([4, 1, 2] if rank == 0 else [3, 2])
+        ok &= calls == {"all_gather": 1, "other": 0}
         for w, r in zip(Ws, res):
-            ok &= torch.equal(r.weight_packed, (w[:, :4] * 1000).to(torch.int32))
-            ok &= torch.equal(r.weight_scale, w[:, :2].to(torch.bfloat16))
-            ok &= r.weight_zero_point is None and torch.equal(r.dequantized(torch.float32), w * 2)
-            ok &= r.weight_shape.tolist() == [w.shape[0], 8]
+            if bits == 4:
+                ok &= torch.equal(r.weight_packed, (w[:, :2].float() * 1000).to(torch.int32)) and r.weight_q is None
+            else:
+                ok &= torch.equal(r.weight_q, levels(w)) and r.weight_packed is None
+            ok &= torch.equal(r.weight_scale, w[:, :2]) and r.weight_scale.dtype == wdt
+            ok &= (r.weight_zero_point is None) if symmetric else torch.equal(r.weight_zero_point, levels(w)[:, 3:5])
+            ok &= (r.weight_g_idx is None) if actorder != "group" else torch.equal(r.weight_g_idx, perm)
+            ok &= torch.equal(r.dequantized(wdt), w * 2)
+            ok &= r.weight_shape.tolist() == [w.shape[0], K]
+        # a result that does not look like the layout every rank assumed is refused, not mis-sliced
+        if rank == 0:
+            qa_bad = types.SimpleNamespace(actorder=actorder, num_bits=bits, symmetric=symmetric, kernel_group_size=4)
+            try:
+                sh.gptq_quantize_row_split(Ws[1:2], None, qa_bad)
+                ok = False
+            except RuntimeError as e:
+                ok &= "layout every rank assumes" in str(e)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-def test_row_split_gather_world2_gloo():
+@pytest.mark.parametrize("variant", [(4, True, "static", torch.float32), (4, False, "group", torch.bfloat16),
+                                     (8, False, None, torch.float16)],
+                         ids=["w4-sym-static-f32", "w4-asym-group-bf16", "w8-asym-f16"])
+def test_row_split_gather_world2_gloo(variant):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_row_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_row_split_worker, args=(r, 2, port, q, variant)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
