@@ -210,6 +210,11 @@ int qt_sgemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, co
                     int64_t ldcin, float* Cout, int64_t ldcout, int M, int N, int kdim, int skip_zero_k,
                     int mode, int allow_split_k, void* workspace, size_t workspace_bytes, qt_stream_t stream);
 
+/* Host-only self-check of the Gram kernel's tile table for K (runs without a GPU): 0 if every lower-triangular
+ * 256 x 256 tile appears exactly once.  Also returns the distinct 256-channel panels per 32-entry chunk (one XCD's
+ * workgroups) and per 256-entry round (the chip), summed over the table -- the locality figures DESIGN.md 4.1 quotes. */
+int qt_xtx_tile_table_check(int K, int* n_tiles_out, int* chunk_panels_out, int* round_panels_out);
+
 /* ---- scale * <H, X^T X>_F without storing X^T X (the Gram kernel's epilogue multiplies its tile with H's;
  * building block of a12's search loss <X^T X, D^T D>; exposed for tests) -----------------------------
  * X [n_tokens, K] bf16 / fp16 with ldx == K and n_tokens % 64 == 0; H [K, K] fp32, lower triangle read.
@@ -230,7 +235,6 @@ int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, fl
 /* Host-only self-check of the bf16x3 block-row planner (runs without a GPU): 0 if every k chunk of every tile is
  * covered exactly once and the slab / reduction tables are consistent, else a negative code. */
 int qt_gemm3_plan_check(int Tm, int Tn, int c_end, int tri, int* n_items_out, int* n_slabs_out, int* longest_out);
-
 /* ---- measurement aid (bench.py roofline leg; not part of the reference surface) -------------
  * When enabled, HIP events are recorded on the launch stream immediately around the named
  * kernel; qt_profile_read synchronises them, returns the summed device time and the launch

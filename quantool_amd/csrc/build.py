@@ -94,8 +94,26 @@ def audit_m0(src: Path) -> None:
         elif not inside and "m0" in line.split(";")[0].replace("_m0", ""):
             raise RuntimeError(f"{src.name}: compiler-generated use of M0 at {asm.name}:{n}: {line.strip()!r} -- "
                                "the LDS-DMA helpers must save/restore M0 again")
+    audit_spills(src.name, asm.read_text())
     asm.unlink()
     stamp.write_text(want)
+
+
+# kernels whose inner loops are hand-scheduled around a fixed register budget: a spill there is a silent 20-30 %
+# (round 3: wrapping gemm3_kernel's body in an item loop let LICM hoist 128 epilogue addresses -> 179 spills)
+NO_SPILL_KERNELS = ("xtx_kernel", "xtx16_kernel", "gemm3_kernel", "sgemm_ring_kernel")
+
+
+def audit_spills(src_name: str, asm_text: str) -> None:
+    """Fail the build when one of NO_SPILL_KERNELS uses scratch (the kernel metadata hipcc -S prints)."""
+    name = None
+    for line in asm_text.splitlines():
+        t = line.strip()
+        if t.startswith(".name:"):
+            name = t.split(":", 1)[1].strip()
+        elif name and t.startswith((".vgpr_spill_count:", ".private_segment_fixed_size:")):
+            if int(t.split(":", 1)[1]) != 0 and any(k in name for k in NO_SPILL_KERNELS):
+                raise RuntimeError(f"{src_name}: {name} spills ({t}) -- its schedule assumes every value stays in registers")
 
 
 def build(verbose: bool = False) -> Path:

@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int BS = 128;    // upstream block_size default
-constexpr int SWEEP_MAX_BATCH = 4;  // blocks whose far update may be merged into one pass over W
+constexpr int SWEEP_MAX_BATCH = 8;  // blocks whose far update may be merged into one pass over W (workspace is sized for it)
 constexpr int SB = 32;     // register sub-block
 constexpr int ROWS = 128;  // rows (lanes) per workgroup: 2 waves
 constexpr size_t SWEEP_LDS = (size_t)(BS * BS + BS * ROWS + 2 * BS) * sizeof(float);
@@ -449,9 +449,12 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
     // (k = 128, few columns); everything to the right of the batch gets the batch's chains in ONE
     // pass over W (chain_len = 128: same roundings, in the same order, as one pass per block), so
     // the read-modify-write traffic on W drops by the batch size.
-    static const int batch_blocks = [] {
+    // Batch size: 4 blocks, 8 from K = 8192 up -- a longer batch halves the far update's traffic on W again but puts
+    // more near-update columns between two block kernels (K = 14336 / R = 4096: 11.74 -> 11.35 ms; K = 4096 /
+    // R = 28672: 5.9 -> 6.0 ms, profiles/r03_sweep_batch_ab.txt).  The bits do not depend on it.  QT_SWEEP_BATCH forces it.
+    const int batch_blocks = [&] {
         const char* e = getenv("QT_SWEEP_BATCH");
-        const int b = e ? atoi(e) : 4;
+        const int b = e ? atoi(e) : (K >= 8192 ? 8 : 4);
         return b < 1 ? 1 : (b > SWEEP_MAX_BATCH ? SWEEP_MAX_BATCH : b);
     }();
     const int prio = qt_chain_prio();

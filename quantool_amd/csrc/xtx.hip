@@ -675,7 +675,7 @@ struct XtxPlan {
 // super-tiles inside a macro block, row-major inside a super-tile.  Off the diagonal 32 consecutive entries = one
 // super-tile (12 distinct panels) and 256 = one macro block (32 panels); the ragged diagonal macro blocks shift the
 // chunk boundaries, which is where the order above gains.
-// Lower-triangular tiles in locality order (the default since round 3; QT_XTX_ORDER=0 = the round-1/2 order below):
+// Lower-triangular tiles in locality order (QT_XTX_ORDER=1; the first round-3 order):
 // blocks of 8 consecutive panels, block rows walked in PAIRS (a, a + 1) column by column -- (a, b) and (a + 1, b)
 // share their column panels -- diagonal blocks as row-major triangles, off-diagonal blocks as 4 x 8 super-tiles.
 // What it buys: the 32 workgroups of an XCD take 32 consecutive entries, and a staged panel is an L2 hit for all
@@ -708,12 +708,69 @@ static void xtx_tile_order_pairs(int nt, std::vector<int>& tab) {
     }
 }
 
+// The default for K >= 5632 (QT_XTX_ORDER=2 forces it, 1 = the pairs order above, 0 = the round-1/2 order below): the pairs walk
+// with every piece a multiple of 32 entries, so that a 32-entry chunk never straddles two super-tiles.  The pairs
+// order emits a diagonal block as its 36-tile triangle, which shifts every later 4 x 8 super-tile by 4 entries
+// against the 32-entry chunks of an XCD (a chunk then spans two super-tiles: 14 panels on average instead of 12).
+// Here a diagonal block gives its first 32 tiles (rows 0..6 and the first 4 of row 7: 8 panels) as one chunk, placed
+// right after its block-row pair's off-diagonal blocks; the 4 tiles left of each triangle, a ragged last block row
+// (K not a multiple of 2048) and its triangle go to the end of the table, where misalignment hurts nothing after it.
+// Distinct panels per 32-entry chunk, summed (tools/xtx_tile_order_eval.py): K = 14336: 701 -> 588 (best-case L2
+// hit 78.0 % -> 81.6 %; 588 = 42 super-tiles x 12 + 7 triangles x 8 + 28 left-over tiles); per round of 256 entries
+// 255 -> 232; K = 28672: 2659 -> 2352; K = 4096: 53 -> 48.
+static void xtx_tile_order_aligned(int nt, std::vector<int>& tab) {
+    const int m = 8, nb = (nt + m - 1) / m;
+    const bool ragged = nt % m != 0;
+    const int nfull = ragged ? nb - 1 : nb;
+    std::vector<int> left;
+    auto blk = [&](int a, int b) {
+        const int r0 = a * m, r1 = std::min(nt, r0 + m), c0 = b * m, c1 = std::min(nt, c0 + m);
+        for (int si = r0; si < r1; si += 4)
+            for (int ti = si; ti < std::min(si + 4, r1); ++ti)
+                for (int tj = c0; tj < c1; ++tj) tab.push_back((ti << 16) | tj);
+    };
+    auto tri = [&](int a) {
+        const int r0 = a * m, r1 = std::min(nt, r0 + m);
+        const bool full = r1 - r0 == m;
+        int n = 0;
+        for (int ti = r0; ti < r1; ++ti)
+            for (int tj = r0; tj <= ti; ++tj, ++n) (full && n < 32 ? tab : left).push_back((ti << 16) | tj);
+    };
+    for (int a = 0; a < nfull; a += 2) {
+        if (a + 1 < nfull) {
+            for (int b = 0; b < a; ++b) {
+                blk(a, b);
+                blk(a + 1, b);
+            }
+            blk(a + 1, a);
+            tri(a);
+            tri(a + 1);
+        } else {
+            for (int b = 0; b < a; ++b) blk(a, b);
+            tri(a);
+        }
+    }
+    if (ragged) {
+        for (int b = 0; b < nb - 1; ++b) blk(nb - 1, b);
+        tri(nb - 1);
+    }
+    tab.insert(tab.end(), left.begin(), left.end());
+}
+
 void xtx_tile_order(int nt, std::vector<int>& tab) {
     tab.clear();
     {
         const char* e = getenv("QT_XTX_ORDER");
-        if (!(e && atoi(e) == 0)) {
+        // below one full round of tiles every workgroup is a token slice of a tile and the 32-entry chunks wrap
+        // around the table at a stride that is not a multiple of 32: alignment buys nothing there (K = 4096: the
+        // pairs order measured 2-3 % faster, profiles/r03_xtx_order_ab.txt)
+        const int mode = e ? atoi(e) : (nt * (nt + 1) / 2 >= NUM_CU ? 2 : 1);
+        if (mode == 1) {
             xtx_tile_order_pairs(nt, tab);
+            return;
+        }
+        if (mode != 0) {
+            xtx_tile_order_aligned(nt, tab);
             return;
         }
     }
@@ -784,6 +841,38 @@ const int* xtx_host_table(int K, int n_tiles) {
 }
 
 }  // namespace
+
+// Host-only self-check of the tile table (runs without a GPU): every lower-triangular 256 x 256 tile exactly once.
+extern "C" int qt_xtx_tile_table_check(int K, int* n_tiles_out, int* chunk_panels_out, int* round_panels_out) {
+    if (K <= 0) return QT_ERR_INVALID;
+    const int nt = (K + BT - 1) / BT;
+    std::vector<int> tab;
+    xtx_tile_order(nt, tab);
+    if ((long)tab.size() != (long)nt * (nt + 1) / 2) return -2;
+    std::vector<char> seen((size_t)nt * nt, 0);
+    for (int e : tab) {
+        const int ti = e >> 16, tj = e & 0xFFFF;
+        if (ti >= nt || tj > ti) return -3;
+        if (seen[(size_t)ti * nt + tj]++) return -4;
+    }
+    // distinct panels per chunk of `size` consecutive entries, summed (what one XCD / the chip stages together)
+    auto panels = [&](int size) {
+        int total = 0;
+        std::vector<int> mark(nt, -1);
+        for (size_t c = 0; c < tab.size(); c += size)
+            for (size_t i = c; i < std::min(tab.size(), c + size); ++i)
+                for (int x : {tab[i] >> 16, tab[i] & 0xFFFF})
+                    if (mark[x] != (int)(c / size)) {
+                        mark[x] = (int)(c / size);
+                        ++total;
+                    }
+        return total;
+    };
+    if (n_tiles_out) *n_tiles_out = (int)tab.size();
+    if (chunk_panels_out) *chunk_panels_out = panels(32);
+    if (round_panels_out) *round_panels_out = panels(NUM_CU);
+    return 0;
+}
 
 extern "C" size_t qt_xtx_workspace_bytes(int64_t n_tokens, int K) {
     if (n_tokens <= 0 || K <= 0) return 0;

@@ -72,6 +72,7 @@ SIGNATURES = {
     "qt_xtx_dot": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_double, c_void_p, c_int, c_void_p,
                            c_size_t, c_void_p]),
     "qt_gemm3_plan_check": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "qt_xtx_tile_table_check": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "qt_gemm3_tn_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "qt_gemm3_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                 c_void_p, c_size_t, c_void_p]),

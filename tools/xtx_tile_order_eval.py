@@ -42,12 +42,53 @@ def order_pairs(nt, m=8):
     return tab
 
 
+def order_aligned(nt, m=8):
+    """xtx_tile_order_aligned: every piece a multiple of 32 entries; 4 left-over tiles per diagonal triangle and a
+    ragged last block row at the end."""
+    nb = (nt + m - 1) // m
+    ragged = nt % m != 0
+    nfull = nb - 1 if ragged else nb
+    tab, left = [], []
+
+    def blk(a, b):
+        r0, r1, c0, c1 = a * m, min(nt, a * m + m), b * m, min(nt, b * m + m)
+        for si in range(r0, r1, 4):
+            tab.extend((ti, tj) for ti in range(si, min(si + 4, r1)) for tj in range(c0, c1))
+
+    def tri(a):
+        r0, r1 = a * m, min(nt, a * m + m)
+        t = [(ti, tj) for ti in range(r0, r1) for tj in range(r0, ti + 1)]
+        if r1 - r0 == m:
+            tab.extend(t[:32])
+            left.extend(t[32:])
+        else:
+            left.extend(t)
+
+    for a in range(0, nfull, 2):
+        if a + 1 < nfull:
+            for b in range(0, a):
+                blk(a, b)
+                blk(a + 1, b)
+            blk(a + 1, a)
+            tri(a)
+            tri(a + 1)
+        else:
+            for b in range(0, a):
+                blk(a, b)
+            tri(a)
+    if ragged:
+        for b in range(0, nb - 1):
+            blk(nb - 1, b)
+        tri(nb - 1)
+    return tab + left
+
+
 def panels(tab, size):
     return sum(len({x for t in tab[c:c + size] for x in t}) for c in range(0, len(tab), size))
 
 
 for nt in [int(x) for x in sys.argv[1:]] or [16, 32, 56, 112]:
-    for name, tab in (("round 1/2", order_r12(nt)), ("pairs    ", order_pairs(nt))):
+    for name, tab in (("round 1/2", order_r12(nt)), ("pairs    ", order_pairs(nt)), ("aligned  ", order_aligned(nt))):
         assert sorted(tab) == [(i, j) for i in range(nt) for j in range(i + 1)]
         c = panels(tab, 32)
         print(f"nt={nt:4d} {name}: panels per 32-chunk, summed {c:5d} (best-case L2 hit {1 - c / (2 * len(tab)):.3f}); "
