@@ -451,7 +451,7 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
     // the read-modify-write traffic on W drops by the batch size.
     // Batch size: 4 blocks, 8 from K = 8192 up -- a longer batch halves the far update's traffic on W again but puts
     // more near-update columns between two block kernels (K = 14336 / R = 4096: 11.74 -> 11.35 ms; K = 4096 /
-    // R = 28672: 5.9 -> 6.0 ms, profiles/r03_sweep_batch_ab.txt).  The bits do not depend on it.  QT_SWEEP_BATCH forces it.
+    // R = 28672: 5.9 -> 6.0 ms; K = 8192: +-0.5 %, profiles/r03_sweep_batch_ab.txt).  The bits do not depend on it.  QT_SWEEP_BATCH forces it.
     const int batch_blocks = [&] {
         const char* e = getenv("QT_SWEEP_BATCH");
         const int b = e ? atoi(e) : (K >= 8192 ? 8 : 4);
