@@ -192,7 +192,9 @@ def awq_layer(shape, weights, acts, qargs):
 def stage_split(shape, weights, acts, n_samples, smooth=None):
     """Per-stage device time of one step with NOTHING overlapped (one stream, stage after stage, torch events),
     outside the timed region: where a layer's time goes when the streams do not hide the latency-bound chains.
-    The sum is therefore larger than `ms_per_step`."""
+    The sum is therefore larger than `ms_per_step`.  Second result: the stages' achieved rates on their ALGORITHMIC
+    work -- TFLOP/s for the Gram pass (N K (K+1)), the factorisation (2/3 K^3, fp32-equivalent) and the
+    sweep (R K^2), GB/s for the HBM-bound single passes."""
     from quantool_amd.hip import ops
 
     def timed(fn):
@@ -203,7 +205,7 @@ def stage_split(shape, weights, acts, n_samples, smooth=None):
         torch.cuda.synchronize()
         return out, e0.elapsed_time(e1)
 
-    tot = {}
+    tot, work = {}, {}
     for gname, K, lins in shape.groups:
         X = acts[gname]
         wts = weights
@@ -225,8 +227,18 @@ def stage_split(shape, weights, acts, n_samples, smooth=None):
         _, row["pack"] = timed(lambda: ops.pack_int4(Qt, inv))
         for k, v in row.items():
             tot[k] = tot.get(k, 0.0) + v
+        # ALGORITHMIC work of the stages: flops for the MFMA-bound ones, bytes for the single passes
+        N, R = int(X.shape[0]), int(W.shape[0])
+        for k, w in (("gram", N * K * (K + 1)), ("factor", 2 * K ** 3 // 3), ("sweep", R * K * K),
+                     ("prepare", 4 * K * K), ("gather", 6 * R * K), ("qparams", 2 * R * K), ("pack", 3 * R * K // 2)):
+            work[k] = work.get(k, 0) + w
         del G, A, U, Wf, Qt, W
-    return {k: round(v, 3) for k, v in tot.items()}
+    rates = {}
+    for k, w in work.items():
+        if tot.get(k, 0.0) > 0:
+            flops = k in ("gram", "factor", "sweep")
+            rates[k + ("_tflops" if flops else "_gbs")] = round(w / (tot[k] * 1e-3) / (1e12 if flops else 1e9), 1)
+    return {k: round(v, 3) for k, v in tot.items()}, rates
 
 
 def join_streams(dev):
@@ -560,9 +572,9 @@ def main():
                  "(SURVEY 8d)"),
     }
 
-    stages = None
+    stages = stage_rates = None
     if rank == 0 and world == 1 and not awq and not args.no_stage_split:
-        stages = stage_split(shape, weights, acts, args.samples, smooth)
+        stages, stage_rates = stage_split(shape, weights, acts, args.samples, smooth)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not awq and args.model == "llama-3-8b":
@@ -611,6 +623,7 @@ def main():
             },
             "roofline": roofline,
             "stages_ms_isolated": stages,
+            "stages_rate_isolated": stage_rates,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
