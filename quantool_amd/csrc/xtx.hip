@@ -270,8 +270,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         const char* base = ring + S * UNIT_BYTES;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) fa[mi] = tr_load8(base + aoff[mi]);
+#ifdef QT_XTX_ABL_LDS    // lab builds only, TIMING-ONLY (wrong results): five fragment reads per phase instead of six
+        fb[0] = tr_load8(base + boff[0]);
+        fb[1] = fb[0];
+#else
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) fb[ni] = tr_load8(base + boff[ni]);
+#endif
         if (STEADY) {
             issue_running(ISLOT);
             wait_vmcnt<10>();   // everything up to unit u+1 has landed; 5 units stay in flight
@@ -287,8 +292,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void xtx_kernel(XtxParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+#ifdef QT_XTX_ABL_HALF   // lab builds only, TIMING-ONLY (wrong results): half of the MFMAs of every phase
+        constexpr int MI_N = 2;
+#else
+        constexpr int MI_N = 4;
+#endif
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI_N; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 acc[mi][ni] = mfma16<F16>(fa[mi], fb[ni], acc[mi][ni]);
