@@ -121,22 +121,42 @@ def smooth_group(lins, weights, X, norm_vec, alpha=0.5):
 def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0, per_sample=False, smooth=None):
     """One step: the hot path over one decoder layer.  Returns the packed outputs.
 
-    The layer's Linear groups are independent, so each runs on its own HIP stream: the
-    latency-bound factorisation / sweep chains of one group overlap the MFMA-bound Gram pass of
-    another.  The largest-K group is issued first (longest chain).  `lane` selects one of two
-    stream sets so that two consecutive layers (independent units in this per-Linear mode, exactly
-    as across GPUs) can be in flight at once."""
+    The layer's Linear groups are independent, so each group's chain (factorise, sweep, pack) runs on
+    its own HIP stream: the latency-bound chains of one group overlap the MFMA-bound work of another.
+    The Gram passes share one further stream, smallest in_features first (below).  `lane` selects one
+    of two stream sets so that two consecutive layers (independent units in this per-Linear mode,
+    exactly as across GPUs) can be in flight at once."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
 
     dev = next(iter(acts.values())).device
     outs = {}
     groups = sorted(shape.groups, key=lambda g: -g[1]) if overlap else list(shape.groups)
     main = torch.cuda.current_stream(dev)
-    for gi, (gname, K, lins) in enumerate(groups):
-        if overlap:
+    # Gram passes of the layer on ONE stream of their own, smallest in_features first; the chains (factorise, sweep,
+    # pack) on a stream per group behind them.  The Gram kernel fills the chip by itself: four of them launched at
+    # once only take turns on the CUs, while one after the other each runs at its stand-alone rate and the short
+    # groups' chains still start within the first milliseconds (same box, 12 steps: 78.9 ms/step with the Gram
+    # launches at 0.50 of the MFMA peak vs 79.5 ms at 0.34 with a Gram pass per group stream,
+    # profiles/r03_stream_policy_sweep.txt).  QT_BENCH_XTX_STREAM: "lane" (default; one Gram stream per layer in
+    # flight), "group" (rounds 1-2: the Gram pass on its group's stream), "shared" (one for both layers in flight),
+    # "prio" (as lane, high stream priority: slower); QT_BENCH_XTX_ORDER=big issues the largest group first.
+    # Per-sample calls are staged by many tiny copies, which one stream would put end to end for all four groups
+    # (86.3 vs 83.3 ms/step): that mode keeps the Gram sums on the group streams, as engine/oneshot.py does.
+    xmode = os.environ.get("QT_BENCH_XTX_STREAM", "group" if per_sample else "lane") if overlap else "group"
+    sx = None
+    if xmode in ("shared", "prio", "lane"):
+        key = (dev.index, "xtx") if xmode == "shared" else (dev.index, "xtx", lane)
+        if key not in _STREAMS:
+            _STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1 if xmode == "prio" else 0)
+        sx = _STREAMS[key]
+        sx.wait_stream(main)
+    slot_of = {g[0]: gi % 4 for gi, g in enumerate(groups)}      # largest in_features -> slot 0, as in rounds 1-2
+    order = groups if (sx is None or os.environ.get("QT_BENCH_XTX_ORDER") == "big") else sorted(groups, key=lambda g: g[1])
+    for gname, K, lins in order:      # a group's chain is issued right behind its Gram pass (the host never runs ahead
+        if overlap:                   # of the GPU by a whole layer of per-sample Gram calls)
             # stream slots per layer: "all4" = one per group; "two" = the largest-K group alone, the rest
             # share one stream (diagnostic knob; default all4)
-            slot = gi % 4 if os.environ.get("QT_BENCH_GROUPING", "all4") == "all4" else min(gi, 1)
+            slot = slot_of[gname] if os.environ.get("QT_BENCH_GROUPING", "all4") == "all4" else min(slot_of[gname], 1)
             if (dev.index, lane, slot) not in _STREAMS:
                 # QT_BENCH_CHAIN_PRIO=1 (diagnostic): the chain streams at high priority
                 prio = -1 if os.environ.get("QT_BENCH_CHAIN_PRIO") == "1" else 0
@@ -145,28 +165,20 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
             st.wait_stream(main)
         else:
             st = main
-        xmode = os.environ.get("QT_BENCH_XTX_STREAM", "group") if overlap else "group"
-        if xmode in ("shared", "prio", "lane"):
-            # Gram passes on their own stream(s): "shared" = one for everything (they are the MFMA-bound
-            # kernels and gain nothing from running against each other), "lane" = one per layer in flight,
-            # "prio" = one per layer in flight at high stream priority
-            key = (dev.index, "xtx") if xmode == "shared" else (dev.index, "xtx", lane)
-            if key not in _STREAMS:
-                _STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1 if xmode == "prio" else 0)
-            sx = _STREAMS[key]
-            sx.wait_stream(main)
-            with torch.cuda.stream(sx):
-                acc = HessianAccumulator(K, dev)   # fresh: its later use is on another stream
-                accumulate(acc, acts[gname], n_samples, per_sample)   # (diagnostic stream policies: no smoothing stage)
-            acc.G.record_stream(st)
-            st.wait_stream(sx)
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(sx if sx is not None else st):
             X, wts = acts[gname], weights
             if smooth and gname in smooth:
                 wts, X = smooth_group(lins, weights, X, smooth[gname])
-            if xmode == "group":
-                acc = _accumulator(K, dev, lane, gi % 4)
-                accumulate(acc, X, n_samples, per_sample)
+            # on the Gram stream a fresh accumulator (read later on the group's stream: record_stream below)
+            acc = HessianAccumulator(K, dev) if sx is not None else _accumulator(K, dev, lane, slot_of[gname])
+            accumulate(acc, X, n_samples, per_sample)
+        if sx is not None:
+            ev = torch.cuda.Event()
+            ev.record(sx)
+            st.wait_event(ev)
+            for t in [acc.G] + ([wts[n] for n, _ in lins] if wts is not weights else []):
+                t.record_stream(st)      # allocated on the Gram stream, read on this one
+        with torch.cuda.stream(st):
             res = gptq_quantize_shared([wts[n] for n, _ in lins], acc, qargs)
             for (lname, _), r in zip(lins, res):
                 outs[f"{lname}.weight_packed"] = r.weight_packed

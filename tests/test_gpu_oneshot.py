@@ -86,3 +86,51 @@ def test_plugin_quantize_on_linear_calibration_set(dev, oracle, tmp_path, monkey
     assert torch.equal(solo.weight_packed.cpu(), sd["layers.0.q_proj.weight_packed"])
     quantizer.save_pretrained(str(tmp_path / "export"))
     assert (tmp_path / "export" / "model.safetensors").exists()
+
+
+def test_gram_stream_and_group_stream_routes_give_the_single_stream_result(dev):
+    """`_oneshot_linears` puts the Gram sum of a group whose activations arrive in long batches (>= 16 384 rows) on
+    the shared Gram stream and its chain on a group stream behind an event; groups fed by short batches keep both on
+    their group stream (engine/streams.py).  Whatever the route, the results equal a plain one-stream run bit for
+    bit -- including a SmoothQuant stage, whose rescaled weights cross from the Gram stream to the chain's."""
+    from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
+    from quantool_amd.engine.modifiers import GPTQModifier, SmoothQuantModifier
+    from quantool_amd.engine.oneshot import LinearCalibrationSet, LinearGroup, oneshot
+    from quantool_amd.engine.schemes import QuantArgs
+
+    torch.manual_seed(3)
+    n_long = HessianAccumulator.DIRECT_TOKENS
+    shapes = {"a": (512, [("a.q", 96), ("a.k", 32)], [n_long]),              # one long batch: Gram stream
+              "b": (256, [("b.up", 160)], [n_long, n_long]),                 # two long batches: Gram stream
+              "c": (384, [("c.o", 64)], [64] * 6),                           # short batches: staged, group stream
+              "d": (1024, [("d.down", 48)], [n_long])}
+    groups, ref = [], {}
+    for gname, (K, lins, batches) in shapes.items():
+        Xs = [torch.randn(n, K, device=dev).to(torch.bfloat16) for n in batches]
+        Ws = {n: (torch.randn(r, K, device=dev) * 0.02).to(torch.bfloat16) for n, r in lins}
+        groups.append(LinearGroup(gname, Xs if len(Xs) > 1 else Xs[0], Ws, num_samples=len(batches)))
+        acc = HessianAccumulator(K, dev)
+        for x in Xs:
+            acc.add(x, num_samples=1)
+        res = gptq_quantize_shared([Ws[n] for n, _ in lins], acc, QuantArgs(actorder="static"))
+        for (n, _), r in zip(lins, res):
+            ref[n] = (r.weight_packed.clone(), r.weight_scale.clone())
+    torch.cuda.synchronize()
+    out = oneshot(model=LinearCalibrationSet(groups), recipe=GPTQModifier(scheme="W4A16"))
+    torch.cuda.synchronize()
+    for n, (packed, scale) in ref.items():
+        r = out.results[n]
+        assert torch.equal(r.weight_packed, packed) and torch.equal(r.weight_scale, scale), n
+    # twice in a row (streams and workspaces are cached per process) and with a smoothing stage on a long-batch group
+    K = 512
+    X = torch.randn(n_long, K, device=dev).to(torch.bfloat16)
+    W = {"s.q": (torch.randn(64, K, device=dev) * 0.02).to(torch.bfloat16)}
+    v = torch.rand(K, device=dev).to(torch.bfloat16) + 0.5
+    runs = []
+    for _ in range(2):
+        g = LinearGroup("s", X, {k: w.clone() for k, w in W.items()}, smooth_vectors={"s.norm": v.clone()}, num_samples=4)
+        o = oneshot(model=LinearCalibrationSet([g] + groups[:1]), recipe=[SmoothQuantModifier(smoothing_strength=0.5),
+                                                                        GPTQModifier(scheme="W4A16")])
+        torch.cuda.synchronize()
+        runs.append((o.results["s.q"].weight_packed.clone(), o.results["s.q"].weight_scale.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
