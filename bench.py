@@ -209,7 +209,14 @@ def stage_split(shape, weights, acts, n_samples, smooth=None):
     sweep (R K^2), GB/s for the HBM-bound single passes."""
     from quantool_amd.hip import ops
 
-    def timed(fn):
+    def timed(fn, undo=None):
+        # once untimed first: a stage's first call at a new size pays for its buffers (multi-GB hipMallocs at
+        # K = 28672 are hundreds of ms of host time with the GPU idle between the two events)
+        warm = fn()
+        del warm
+        if undo is not None:
+            undo()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn()
@@ -227,7 +234,7 @@ def stage_split(shape, weights, acts, n_samples, smooth=None):
         Ws = [wts[n] for n, _ in lins]
         W = torch.cat(Ws, 0) if len(Ws) > 1 else Ws[0]
         G = torch.zeros((K, K), dtype=torch.float32, device=X.device)
-        _, row["gram"] = timed(lambda: ops.xtx_accumulate(X, G))
+        _, row["gram"] = timed(lambda: ops.xtx_accumulate(X, G), undo=G.zero_)
         diag = ops.hessian_diag(G, n_samples)
         (perm, inv), row["order"] = timed(lambda: ops.argsort_desc(diag))
         (A, dead, _), row["prepare"] = timed(lambda: ops.hessian_prepare(G, n_samples, 0.01, perm))
