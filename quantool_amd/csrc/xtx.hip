@@ -767,22 +767,26 @@ static void xtx_tile_order_aligned(int nt, std::vector<int>& tab) {
     tab.insert(tab.end(), left.begin(), left.end());
 }
 
+// which walk: QT_XTX_ORDER, read per call (the tests and A/B tools switch it inside one process)
+static int xtx_order_mode(int nt) {
+    const char* e = getenv("QT_XTX_ORDER");
+    const int mode = e ? atoi(e) : (nt * (nt + 1) / 2 >= NUM_CU ? 2 : 1);
+    return mode < 0 || mode > 2 ? 2 : mode;
+}
+
 void xtx_tile_order(int nt, std::vector<int>& tab) {
     tab.clear();
-    {
-        const char* e = getenv("QT_XTX_ORDER");
-        // below one full round of tiles every workgroup is a token slice of a tile and the 32-entry chunks wrap
-        // around the table at a stride that is not a multiple of 32: alignment buys nothing there (K = 4096: the
-        // pairs order measured 2-3 % faster, profiles/r03_xtx_order_ab.txt)
-        const int mode = e ? atoi(e) : (nt * (nt + 1) / 2 >= NUM_CU ? 2 : 1);
-        if (mode == 1) {
-            xtx_tile_order_pairs(nt, tab);
-            return;
-        }
-        if (mode != 0) {
-            xtx_tile_order_aligned(nt, tab);
-            return;
-        }
+    // below one full round of tiles every workgroup is a token slice of a tile and the 32-entry chunks wrap around
+    // the table at a stride that is not a multiple of 32: alignment buys nothing there (K = 4096: the pairs order
+    // measured 0-3 % faster, profiles/r03_xtx_order_ab.txt) -- see xtx_order_mode
+    const int mode = xtx_order_mode(nt);
+    if (mode == 1) {
+        xtx_tile_order_pairs(nt, tab);
+        return;
+    }
+    if (mode == 2) {
+        xtx_tile_order_aligned(nt, tab);
+        return;
     }
     for (int bi = 0; bi < nt; bi += 16)
         for (int bj = 0; bj <= bi + 15 && bj < nt; bj += 16)
@@ -836,9 +840,10 @@ XtxPlan xtx_plan(int64_t n_tokens, int K) {
 // hipMemcpyAsync into the caller's workspace is a real asynchronous copy, not a staged one.
 const int* xtx_host_table(int K, int n_tiles) {
     static std::mutex m;
-    static std::map<int, int*> tabs;
+    static std::map<std::pair<int, int>, int*> tabs;      // one table per (K, walk)
     std::lock_guard<std::mutex> lock(m);
-    auto it = tabs.find(K);
+    const std::pair<int, int> key(K, xtx_order_mode((K + BT - 1) / BT));
+    auto it = tabs.find(key);
     if (it != tabs.end()) return it->second;
     std::vector<int> v;
     xtx_tile_order((K + BT - 1) / BT, v);
@@ -846,7 +851,7 @@ const int* xtx_host_table(int K, int n_tiles) {
     int* pinned = nullptr;
     if (hipHostMalloc((void**)&pinned, v.size() * sizeof(int), hipHostMallocDefault) != hipSuccess) return nullptr;
     for (size_t i = 0; i < v.size(); ++i) pinned[i] = v[i];
-    tabs[K] = pinned;
+    tabs[key] = pinned;
     return pinned;
 }
 

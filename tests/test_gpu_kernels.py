@@ -43,6 +43,30 @@ def test_xtx_matches_f64_gram(ops, oracle, dev, n_tokens, K):
     assert np.all(np.abs(got2 - 2 * want) <= 2e-5 * np.tril(dscale) + 1e-30)
 
 
+@pytest.mark.parametrize("K,order", [(5888, None), (6400, None), (8192, None), (5888, "1"), (5888, "0"), (4096, "2")])
+def test_xtx_tile_tables_at_and_above_one_round_of_tiles(ops, dev, monkeypatch, K, order):
+    """From one full round of tiles up (K >= 5632) the tile table is the 32-aligned walk; K = 5888 (23 panels: a
+    ragged last block row and 20 left-over tiles at the table's end) and 6400 (25 panels) are its awkward shapes,
+    8192 the first with whole rounds AND a remainder split over token chunks.  Each lower tile, diagonal ones
+    included, against an fp32 torch product; the other orders (QT_XTX_ORDER) on the same input must agree to the
+    bit (a tile's value does not depend on where the table lists it; tables are cached per (K, order))."""
+    n = 1536
+    torch.manual_seed(K)
+    X = torch.randn(n, K, device=dev).to(torch.bfloat16)
+    Gd = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, Gd)                      # the default order of this K
+    if order is not None:
+        monkeypatch.setenv("QT_XTX_ORDER", order)
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    torch.cuda.synchronize()
+    ref = X.float().t() @ X.float()
+    d = torch.sqrt(torch.outer(torch.diagonal(ref), torch.diagonal(ref)))
+    err = ((torch.tril(G) - torch.tril(ref)).abs() / d).max().item()
+    assert err <= 1e-5, err
+    assert torch.equal(torch.tril(G), torch.tril(Gd))
+
+
 def test_xtx_is_deterministic_and_handles_3d_input(ops, dev):
     torch.manual_seed(0)
     X = torch.randn(4, 96, 256, device=dev).to(torch.bfloat16)
