@@ -107,6 +107,12 @@ def load() -> ctypes.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "There is no CPU fallback for the quantization path."
         )
+    # torch first: it ships its own libamdhip64, and the process must end up with ONE HIP runtime -- the one that
+    # owns torch's device context.  Loaded before torch, this library binds the system runtime (LD_LIBRARY_PATH)
+    # instead, whose hipHostMalloc then has no context to pin memory for (seen as "could not build the tile table"
+    # when build() and smoke() ran in one process).
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
