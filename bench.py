@@ -511,6 +511,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kept.append(step(_))
+    t_host = time.perf_counter() - t0             # host time to enqueue the steps (the GPU runs behind it)
     join_streams(dev)
     torch.cuda.synchronize()
     t_compute = time.perf_counter() - t0          # this rank's own steps, before the collective
@@ -633,6 +634,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "per_rank_compute_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
             "gather_ms": round((elapsed - max(per_rank)) * 1e3, 3) if world > 1 else 0.0,
+            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {
