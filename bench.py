@@ -190,11 +190,11 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
 def awq_layer(shape, weights, acts, qargs):
     """One step of the AWQ mode (BASELINE.json configs[2]): the 20-point per-channel scale search,
     apply, observer + round-to-nearest + int4 pack for the four mappings of one decoder layer."""
-    from quantool_amd.engine.awq_linear import awq_quantize_group
+    from quantool_amd.engine.awq_linear import awq_quantize_groups
 
     outs = {}
-    for gname, K, lins in shape.groups:
-        res = awq_quantize_group([weights[n] for n, _ in lins], [acts[gname]], qargs)
+    results = awq_quantize_groups([([weights[n] for n, _ in lins], [acts[gname]]) for gname, K, lins in shape.groups], qargs)
+    for (gname, K, lins), res in zip(shape.groups, results):
         for (lname, _), r in zip(lins, res):
             outs[f"{lname}.weight_packed"] = r.weight_packed
             outs[f"{lname}.weight_scale"] = r.weight_scale

@@ -272,16 +272,21 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
             pool.join()
         mod = gp
     else:
-        from .awq_linear import awq_quantize_group
+        from .awq_linear import awq_quantize_groups
 
         qargs = aw.weight_args()
+        todo = []
         for g in cal.groups:
             names = [n for n in g.weights if n.split(".")[-1] not in aw.ignore and n not in aw.ignore]
-            if not names:
-                continue
-            res = awq_quantize_group([g.weights[n].to(device) for n in names], _iter_batches(g.activations), qargs,
-                                     n_grid=aw.n_grid, duo_scaling=aw.duo_scaling, device=device)
-            results.update(dict(zip(names, res)))
+            if names:
+                todo.append((names, [g.weights[n].to(device) for n in names], _iter_batches(g.activations)))
+        # every mapping's search is enqueued before the host waits for the first (awq_quantize_groups); in chunks of
+        # eight mappings, so that at most eight Gram matrices are alive at once
+        for c in range(0, len(todo), 8):
+            chunk = todo[c:c + 8]
+            for (names, _, _), res in zip(chunk, awq_quantize_groups([(w, b) for _, w, b in chunk], qargs, n_grid=aw.n_grid,
+                                                                     duo_scaling=aw.duo_scaling, device=device)):
+                results.update(dict(zip(names, res)))
         mod = aw
     return QuantizedLinears(results, recipe, mod.scheme, mod.resolved_scheme.format, qargs.to_config(), list(mod.ignore),
                             smoothed, smoothing_scales)
