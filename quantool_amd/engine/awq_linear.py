@@ -36,6 +36,9 @@ class AWQResult:
 
     def dequantized(self, dtype=torch.float32) -> torch.Tensor:
         """(q - zp) * scale: the weight upstream leaves in the module after the observer pass."""
+        if self.Qt is None:
+            raise RuntimeError("the integer levels of this result were released (sequential driver, "
+                               "QT_RESULT_DETAIL_BYTES): the module's weight holds the dequantised values")
         return ops.dequantize(self.Qt, self.scale_f32, self.zp_f32, self.g_of_col, None, dtype)
 
 

@@ -131,6 +131,9 @@ class GPTQResult:
 
     def dequantized(self, dtype=torch.float32) -> torch.Tensor:
         """(q - zp) * scale in original column order -- what upstream writes back to the module."""
+        if self.Qt is None:
+            raise RuntimeError("the integer levels of this result were released (sequential driver, "
+                               "QT_RESULT_DETAIL_BYTES): the module's weight holds the dequantised values")
         return ops.dequantize(self.Qt, self.scale_f32, self.zp_f32, self.g_of_col, self.col_src, dtype)
 
 

@@ -353,7 +353,7 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
     ph.stop("first-layer inputs")
 
     prefix_of = {id(m): n for n, m in model.named_modules()}
-    results: Dict[str, Any] = {}
+    results: Dict[str, Any] = _ResultStore()
     with torch.no_grad():
         for li, layer in enumerate(layers):
             lname = prefix_of[id(layer)]
@@ -513,6 +513,39 @@ class _Phases:
     def report(self):
         if self.on:
             logger.warning("calibration phases: " + ", ".join(f"{k} {v:.3f} s" for k, v in self.acc.items()))
+
+
+#: Beyond what the checkpoint needs (packed words, scales, zero points, g_idx, shape) a result object carries the
+#: integer levels in sweep order and, for AWQ, the rescaled weight -- one to three bytes per weight, kept so that
+#: ``dequantized()`` and the parity tests can look at them.  Over a whole model that is as large as the model itself
+#: (Llama-3-70B-shaped: 68 GiB of levels next to 131 GiB of weights on one 288 GB GPU), so once the detail of the
+#: results kept so far exceeds this many bytes, later results keep only their checkpoint tensors.
+RESULT_DETAIL_BYTES = int(os.environ.get("QT_RESULT_DETAIL_BYTES", str(4 << 30)))
+
+
+class _ResultStore(dict):
+    """name -> result; strips the detail tensors of a result once the store holds RESULT_DETAIL_BYTES of them."""
+
+    _DETAIL = ("Qt", "scaled_weight")
+
+    def __init__(self):
+        super().__init__()
+        self.detail_bytes = 0
+
+    def __setitem__(self, name, r):
+        size = sum(t.numel() * t.element_size() for t in (getattr(r, f, None) for f in self._DETAIL)
+                   if isinstance(t, torch.Tensor))
+        if self.detail_bytes + size > RESULT_DETAIL_BYTES:
+            for f in self._DETAIL:
+                if isinstance(getattr(r, f, None), torch.Tensor):
+                    setattr(r, f, None)      # dequantized() on such a result raises: the module holds that weight
+        else:
+            self.detail_bytes += size
+        super().__setitem__(name, r)
+
+    def update(self, other=(), **kw):
+        for k, v in dict(other, **kw).items():
+            self[k] = v
 
 
 def merge_cache(cache: List[tuple], max_tokens: int) -> List[tuple]:

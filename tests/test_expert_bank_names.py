@@ -86,3 +86,35 @@ def test_dense_save_splits_the_views_of_the_fused_storage(tmp_path):
         assert torch.equal(sd[f"layers.0.experts.{e}.up_proj.weight"], gu[e, I:])
         assert torch.equal(sd[f"layers.0.experts.{e}.down_proj.weight"], dn[e])
     assert not any("gate_up_proj" in k for k in sd)
+
+
+def test_result_store_releases_detail_beyond_its_budget(monkeypatch):
+    """The sequential driver keeps a result's integer levels (and AWQ's rescaled weight) only while the total stays
+    under RESULT_DETAIL_BYTES; later results keep their checkpoint tensors and `dequantized()` says why it cannot."""
+    import types
+
+    import torch
+
+    from quantool_amd.engine import sequential
+    from quantool_amd.engine.gptq_linear import GPTQResult
+
+    monkeypatch.setattr(sequential, "RESULT_DETAIL_BYTES", 3000)
+    store = sequential._ResultStore()
+
+    def result(n):
+        z = torch.zeros(1)
+        return GPTQResult(weight_packed=torch.zeros(4, dtype=torch.int32), weight_q=None, weight_scale=z, weight_zero_point=None,
+                          weight_g_idx=None, weight_shape=torch.tensor([1, 8]), loss=z, info=z, scale_f32=z, zp_f32=z,
+                          Qt=torch.zeros(n, dtype=torch.int8), col_src=None, g_of_col=z)
+
+    store["a"] = result(2000)
+    store.update({"b": result(900)})
+    store["c"] = result(200)                         # 2000 + 900 + 200 > 3000
+    store["d"] = types.SimpleNamespace(Qt=torch.zeros(50, dtype=torch.int8), scaled_weight=torch.zeros(10))   # fits: 2900 + 90 <= 3000
+    assert store["a"].Qt is not None and store["b"].Qt is not None and store["c"].Qt is None
+    assert store["d"].Qt is not None and store.detail_bytes == 2990
+    assert store["c"].weight_packed is not None
+    import pytest
+
+    with pytest.raises(RuntimeError, match="released"):
+        store["c"].dequantized()
