@@ -4,12 +4,13 @@ intermediate 14336, 32 heads / 8 KV heads, vocab 128256; no download) quantised 
 512 calibration samples x 384 random tokens through the quantool plugin API (`QuantizerRegistry.create("gptq")
 .quantize(...)`), then saved as a compressed-tensors checkpoint and read back.
 
-usage: full_model_8b.py [layers [samples [seq [method [level [shape]]]]]]       (defaults: 32 512 384 gptq W4A16 8b)
+usage: full_model.py [layers [samples [seq [method [level [shape]]]]]]       (defaults: 32 512 384 gptq W4A16 8b)
+shape mixtral = Mixtral-8x7B's dimensions (8 experts, top-2): e.g. `32 512 384 smoothquant W4A8 mixtral`.
 shape 70b = Llama-3-70B's dimensions (hidden 8192, intermediate 28672, 64 heads / 8 KV heads; 80 layers = 141 GB of
 bf16 weights, which one MI355X holds): the checkpoint then goes to QT_FULL_MODEL_OUT (default: a temp dir) once only.
 
 Prints wall time of quantize(), of save_pretrained(), the checkpoint size, and a read-back check of one packed
-Linear against the model's own written-back weight.  Numbers: profiles/r03_full_model_8b.txt."""
+Linear against the model's own written-back weight.  Numbers: profiles/r03_full_model.txt."""
 import logging
 import os
 import sys
@@ -35,22 +36,31 @@ level = argv[4] if len(argv) > 4 else "W4A16"
 shape = argv[5] if len(argv) > 5 else "8b"
 dev = torch.device("cuda:0")
 
-hidden, inter, heads = {"8b": (4096, 14336, 32), "70b": (8192, 28672, 64)}[shape]
-cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
-                  num_key_value_heads=8, vocab_size=128256, max_position_embeddings=8192, rope_theta=500000.0,
-                  rms_norm_eps=1e-5, tie_word_embeddings=False)
+if shape == "mixtral":      # Mixtral-8x7B's dimensions: 8 experts, top-2 routing (BASELINE.json configs[4])
+    from transformers import MixtralConfig, MixtralForCausalLM
+
+    cfg = MixtralConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=layers, num_attention_heads=32,
+                        num_key_value_heads=8, num_local_experts=8, num_experts_per_tok=2, vocab_size=32000,
+                        max_position_embeddings=8192, rope_theta=1e6, rms_norm_eps=1e-5, tie_word_embeddings=False)
+    model_cls = MixtralForCausalLM
+else:
+    hidden, inter, heads = {"8b": (4096, 14336, 32), "70b": (8192, 28672, 64)}[shape]
+    cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                      num_key_value_heads=8, vocab_size=128256, max_position_embeddings=8192, rope_theta=500000.0,
+                      rms_norm_eps=1e-5, tie_word_embeddings=False)
+    model_cls = LlamaForCausalLM
 t0 = time.perf_counter()
 torch.manual_seed(0)
 prev = torch.get_default_dtype()
 torch.set_default_dtype(torch.bfloat16)
 try:
     with torch.device(dev):
-        model = LlamaForCausalLM(cfg)
+        model = model_cls(cfg)
 finally:
     torch.set_default_dtype(prev)
 model.eval()
 torch.cuda.synchronize()
-n_lin = sum(p.numel() for n_, p in model.named_parameters() if "proj" in n_)
+n_lin = sum(p.numel() for n_, p in model.named_parameters() if "proj" in n_ or "experts" in n_)
 print(f"model: {layers} layers, {sum(p.numel() for p in model.parameters()) / 1e9:.2f} G parameters "
       f"({n_lin / 1e9:.2f} G in the decoder Linears), built in {time.perf_counter() - t0:.1f} s", flush=True)
 
@@ -61,7 +71,7 @@ with torch.no_grad():
     before = model(input_ids=probe).logits.float()
 
 with tempfile.TemporaryDirectory(dir=os.environ.get("QT_FULL_MODEL_OUT")) as tmp:
-    q = QuantizerRegistry.create(method, model_id=f"synthetic/llama-3-{shape}-shaped")
+    q = QuantizerRegistry.create(method, model_id=f"synthetic/{shape}-shaped")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     q.quantize(model=model, level=level, dataset=data, num_calibration_samples=n_samples, max_seq_length=seq,
@@ -74,7 +84,7 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("QT_FULL_MODEL_OUT")) as tmp
     print(f"peak GPU memory {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB allocated, "
           f"{torch.cuda.max_memory_reserved(dev) / 2**30:.1f} GiB reserved", flush=True)
     saved = tmp + "/saved"
-    if shape == "70b":          # one copy of a 35 GB checkpoint is enough: read back what quantize() wrote
+    if shape != "8b":           # one copy of a 25-40 GB checkpoint is enough: read back what quantize() wrote
         saved = tmp + "/work"
         t0 = time.perf_counter()
     else:
@@ -88,7 +98,7 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("QT_FULL_MODEL_OUT")) as tmp
     with torch.no_grad():
         after = model(input_ids=probe).logits.float()
     print(f"logits relative change on a 64-token probe: {float((after - before).norm() / before.norm()):.3f}", flush=True)
-    if level.upper().startswith("W4"):
+    if level.upper().startswith("W4") and shape != "mixtral":
         # read one packed Linear back and compare with what the driver wrote into the module
         import json
 
