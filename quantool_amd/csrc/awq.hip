@@ -96,14 +96,16 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict_
     out[k] = out[k] + s;
 }
 
-// scales[g][k] for the n_grid ratios g/n_grid (one workgroup):
+// scales[g][k] for the n_grid ratios g/n_grid (one workgroup per ratio: the ratios are independent, and one workgroup
+// walking all twenty took 0.37 ms at K = 14336):
 //   s = clamp(x_mean^r / (w_mean^(1-r) + 1e-4), 1e-4);  s /= sqrt(max s * min s);  nan/inf -> 1
 __global__ __launch_bounds__(1024) void awq_scales_kernel(const float* __restrict__ x_sum, float inv_tokens,
                                                           const float* __restrict__ w_sum, float inv_rows, int K,
                                                           int n_grid, int duo, float* __restrict__ scales) {
     __shared__ float smax[16], smin[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int gi = 0; gi < n_grid; ++gi) {
+    {
+        const int gi = blockIdx.x;
         const float r = (float)gi / (float)n_grid;
         float mx = -INFINITY, mn = INFINITY;
         for (int k = tid; k < K; k += 1024) {
@@ -133,7 +135,6 @@ __global__ __launch_bounds__(1024) void awq_scales_kernel(const float* __restric
             if (!(fabsf(s) <= 3.4028234e38f)) s = 1.0f;  // inf or nan
             scales[(size_t)gi * K + k] = s;
         }
-        __syncthreads();
     }
 }
 
@@ -505,7 +506,7 @@ extern "C" int qt_awq_scales(const float* x_abs_sum, int64_t n_tokens, const flo
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(x_abs_sum && w_sum && scales && K > 0 && n_grid > 0 && n_tokens > 0 && n_rows > 0,
                  "qt_awq_scales: bad arguments");
-    hipLaunchKernelGGL(awq_scales_kernel, dim3(1), dim3(1024), 0, stream, x_abs_sum, (float)(1.0 / (double)n_tokens),
+    hipLaunchKernelGGL(awq_scales_kernel, dim3(n_grid), dim3(1024), 0, stream, x_abs_sum, (float)(1.0 / (double)n_tokens),
                        w_sum, (float)(1.0 / (double)n_rows), K, n_grid, duo_scaling, scales);
     QT_LAUNCH_CHECK();
     return QT_OK;
