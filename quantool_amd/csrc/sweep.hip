@@ -209,7 +209,8 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
 // classes of a quad on disjoint banks).  73 KiB per workgroup of 64 rows, so two workgroups share a CU
 // with room left for a GEMM workgroup.
 constexpr int QL = 4;                 // lanes per row
-constexpr int QROWS = 64;             // rows per workgroup
+constexpr int QROWS = 64;             // rows per workgroup (128: half as many workgroups holding a CU's LDS, but the
+                                      // stage is 9 % slower alone and the bench does not move: 76.7-77.0 vs 76.5-76.9 ms)
 constexpr int QTHREADS = QROWS * QL;  // 256
 constexpr int QM = BS / QL;           // columns per lane: 32
 constexpr int UP_P = QM + 4;          // floats per (c, p) row
@@ -355,18 +356,19 @@ __global__ __launch_bounds__(QTHREADS) void sweep_quad_kernel(float* __restrict_
     const int rowc = valid ? row : R - 1;
     const int nm = cnt >> 2;             // cnt % 4 == 0 (K % 4 == 0)
 
-    {   // the U block, strictly above the diagonal, per (step, lane class); 16 independent float4 loads per thread
+    {   // the U block, strictly above the diagonal, per (step, lane class); NV independent float4 loads per thread
         const float* ublk = U + (size_t)i1 * K + i1;
-        f32x4 v[16];
+        constexpr int NV = BS * BS / 4 / QTHREADS;
+        f32x4 v[NV];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < NV; ++r) {
             const int e4 = tid + QTHREADS * r;                 // float4 index in the 128 x 32 grid
             const int i = e4 >> 5, j = (e4 & 31) * 4;
             const int ic = i < cnt ? i : cnt - 1, jc = j < cnt ? j : cnt - 4;
             v[r] = *(const f32x4*)(ublk + (size_t)ic * K + jc);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < NV; ++r) {
             const int e4 = tid + QTHREADS * r;
             const int i = e4 >> 5, m = e4 & 31, j = m * 4;
             const bool inside = i < cnt && j < cnt;
