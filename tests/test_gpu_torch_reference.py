@@ -53,7 +53,8 @@ def _torch_gptq(Wb, X, gs=128, bs=128, symmetric=True):
     return scale, zp, L[:, torch.argsort(perm)].to(torch.int8)
 
 
-@pytest.mark.parametrize("R,K,S,T,symmetric", [(96, 512, 8, 64, True), (64, 768, 6, 96, False), (128, 1024, 12, 128, True)])
+@pytest.mark.parametrize("R,K,S,T,symmetric", [(96, 512, 8, 64, True), (64, 768, 6, 96, False), (128, 1024, 12, 128, True),
+                                               (1024, 4096, 64, 384, True)])      # a production in_features
 def test_plain_torch_statement_of_the_path_agrees(dev, R, K, S, T, symmetric):
     from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
     from quantool_amd.engine.schemes import QuantArgs
