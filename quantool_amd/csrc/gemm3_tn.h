@@ -44,6 +44,9 @@ struct G3Args {
     int M, N;                    // output extent
     float* C;
     int64_t ldc;
+    // B-side layout when it differs from A's (0 = same as A): pitch, plane stride, column count
+    int64_t ldB = 0, plane_strideB = 0;
+    int colmaxB = 0;
     int mode;                    // G3_SUB / G3_SET: what direct items and the slab reduction do to C
     float* slabs;                // [n_slabs][256*256]
     const G3Item* items;         // device

@@ -35,10 +35,10 @@ constexpr unsigned PB_BITS = 0u | (2u << 2) | (1u << 4) | (0u << 6) | (1u << 8) 
 struct G3Params {
     const char* Apl;
     const char* Bpl;
-    int64_t plane_bytes;
-    int64_t ld2;          // row pitch in bytes
+    int64_t plane_bytes, plane_bytesB;
+    int64_t ld2, ld2B;    // row pitch in bytes (A planes / B planes)
     int64_t rowA0, rowB0;
-    int colA0, colB0, colmax;
+    int colA0, colB0, colmax, colmaxB;
     int M, N;
     float* C;
     int64_t ldc;
@@ -72,22 +72,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
     int colA = p.colA0 + ti * BT + (wave >> 2) * 128 + lch * 8;
     int colB = p.colB0 + tj * BT + (wave >> 2) * 128 + lch * 8;
     colA = colA > p.colmax - 8 ? p.colmax - 8 : colA;   // edge tiles: clamp (masked at the store)
-    colB = colB > p.colmax - 8 ? p.colmax - 8 : colB;
+    colB = colB > p.colmaxB - 8 ? p.colmaxB - 8 : colB;
     const unsigned voffA = (unsigned)((size_t)trow * (size_t)p.ld2 + (size_t)colA * 2);
-    const unsigned voffB = (unsigned)((size_t)trow * (size_t)p.ld2 + (size_t)colB * 2);
+    const unsigned voffB = (unsigned)((size_t)trow * (size_t)p.ld2B + (size_t)colB * 2);
     const unsigned ring_lds = (unsigned)(size_t)(QT_LDS char*)ring;
     const unsigned dst_wave =
         __builtin_amdgcn_readfirstlane(ring_lds + (wave >> 2) * 4096 + (wave & 3) * 1024);
 
     // unit i of the item -> (k chunk, plane product, 16-row slice): scalar source pointers of both panels
-    const int64_t ustride = (int64_t)UT * p.ld2;
+    const int64_t ustride = (int64_t)UT * p.ld2, ustrideB = (int64_t)UT * p.ld2B;
     auto unit_src = [&](int i, const char*& a, const char*& b) {
         const int g = i >> 2, j = i & 3;
         const int c = g / 6, pr = g - 6 * c;
         const int64_t plA = (PA_BITS >> (2 * pr)) & 3u, plB = (PB_BITS >> (2 * pr)) & 3u;
         const int64_t row = (int64_t)(c_lo + c) * CH_ROWS + j * UT;
         a = p.Apl + plA * p.plane_bytes + (p.rowA0 + row) * p.ld2;
-        b = p.Bpl + plB * p.plane_bytes + (p.rowB0 + row) * p.ld2;
+        b = p.Bpl + plB * p.plane_bytesB + (p.rowB0 + row) * p.ld2B;
     };
     auto issue = [&](int i, int slot) {
         const char *a, *b;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
             const unsigned d = dst_wave + (unsigned)ISLOT * UNIT_BYTES;
             glds16_pair2(voffA, voffB, runA, runB, d, d + 8192);
             runA += ustride;
-            runB += ustride;
+            runB += ustrideB;
             wait_vmcnt<10>();
         } else if (u + LEAD < nu) {
             issue(u + LEAD, ISLOT);
@@ -307,6 +307,12 @@ int qt_gemm3_launch(const G3Args& a, hipStream_t stream) {
     p.Bpl = (const char*)a.Bpl;
     p.plane_bytes = a.plane_stride * 2;
     p.ld2 = a.ld * 2;
+    p.plane_bytesB = (a.plane_strideB ? a.plane_strideB : a.plane_stride) * 2;
+    p.ld2B = (a.ldB ? a.ldB : a.ld) * 2;
+    p.colmaxB = a.colmaxB ? a.colmaxB : a.colmax;
+    QT_CHECK_ARG(p.ld2B % 16 == 0 && p.colmaxB >= 8 && (p.plane_bytesB % 16) == 0 &&
+                     (uint64_t)p.ld2B * UT + (uint64_t)p.colmaxB * 2 < ((uint64_t)1 << 32),
+                 "qt_gemm3_launch: B-side pitch %lld / columns %d unsupported", (long long)(p.ld2B / 2), p.colmaxB);
     p.rowA0 = a.rowA0;
     p.rowB0 = a.rowB0;
     p.colA0 = a.colA0;
