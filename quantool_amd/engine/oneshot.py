@@ -13,17 +13,15 @@ returns (``base.py:188``).
 """
 from __future__ import annotations
 
-import json
 import logging
-import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from pathlib import Path
-from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+from typing import Any, Dict, Iterable, List, Optional, Tuple
 
 import torch
 
 from ..hip import ops
-from .gptq_linear import GPTQResult, HessianAccumulator, gptq_quantize_shared
+from .gptq_linear import HessianAccumulator, gptq_quantize_shared
 from .modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
 
 logger = logging.getLogger(__name__)

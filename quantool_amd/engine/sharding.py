@@ -11,7 +11,6 @@ data-path collective.  The only exchange is the gather of the packed state to ra
 """
 from __future__ import annotations
 
-import io
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
