@@ -54,6 +54,58 @@ __global__ __launch_bounds__(256) void build_flipped_kernel(const float* __restr
     A[(size_t)i * K + j] = v;
 }
 
+// The same result in two coalesced passes (K >= 2048).  build_flipped_kernel reads G[max(pa, pb)][min(pa, pb)]: for
+// pb > pa that walks DOWN a column of the lower triangle, one 64-byte sector per 4-byte element (K = 14336: 1.45 ms,
+// ~0.6 TB/s).  A permuted symmetric gather cannot avoid strided accesses on a triangle, so pass 1 writes the full
+// symmetric matrix S (64 x 64 tiles through LDS: the tile and its transpose, both coalesced), and pass 2 takes ONE
+// row of S per output row into LDS and gathers the permuted columns from there.  Pure data movement: every value
+// goes through the same G * c (and the same diagonal fix-up) as in the one-pass kernel, so A is bit-identical.
+__global__ __launch_bounds__(256) void symmetrize_to_kernel(const float* __restrict__ G, int K, float* __restrict__ S) {
+    __shared__ float t[64][65];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    for (int r = ty; r < 64; r += 4) {
+        const int i = bi * 64 + r, j = bj * 64 + tx;
+        t[r][tx] = (i < K && j < K && j <= i) ? G[(size_t)i * K + j] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int i = bi * 64 + r, j = bj * 64 + tx;
+        if (i < K && j < K) {
+            // a diagonal tile holds its lower half only: element (i, j) with j > i is the mirror image t[tx][r]
+            S[(size_t)i * K + j] = (bi == bj && j > i) ? t[tx][r] : t[r][tx];
+        }
+        if (bi != bj) {
+            const int it = bj * 64 + r, jt = bi * 64 + tx;      // transposed tile: S[bj-rows][bi-cols]
+            if (it < K && jt < K) S[(size_t)it * K + jt] = t[tx][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void build_flipped_rows_kernel(const float* __restrict__ S, int K, float c,
+                                                                 const int32_t* __restrict__ perm,
+                                                                 const uint8_t* __restrict__ dead,
+                                                                 const float* __restrict__ stats, float* __restrict__ A) {
+    extern __shared__ __attribute__((aligned(16))) float row[];   // S[pa][0..K)
+    const int i = blockIdx.x;
+    const int a = K - 1 - i;
+    const int pa = perm ? perm[a] : a;
+    const float* src = S + (size_t)pa * K;
+    for (int q = threadIdx.x * 4; q < K; q += 256 * 4) *(f32x4*)(row + q) = *(const f32x4*)(src + q);   // K % 4 == 0
+    __syncthreads();
+    for (int j = i + threadIdx.x; j < K; j += 256) {
+        const int b = K - 1 - j;
+        const int pb = perm ? perm[b] : b;
+        float v = row[pb] * c;
+        if (a == b) {
+            if (dead[a]) v = 1.0f;
+            v = v + stats[0];
+        }
+        A[(size_t)i * K + j] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void diag_only_kernel(const float* __restrict__ G, int K, float c,
                                                         float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,9 +196,16 @@ extern "C" int qt_argsort_desc(const float* values, int K, int32_t* perm, int32_
     return QT_OK;
 }
 
+// two-pass form: K a multiple of 4, one row of S in LDS (<= 160 KiB); QT_PREPARE_TWO_PASS=0 keeps the one-pass kernel
+static bool prepare_two_pass(int K) {
+    const char* e = getenv("QT_PREPARE_TWO_PASS");
+    if (e && atoi(e) == 0) return false;
+    return K >= 2048 && K % 4 == 0 && (size_t)K * 4 <= 160 * 1024;
+}
+
 extern "C" size_t qt_hessian_prepare_workspace_bytes(int K) {
-    (void)K;
-    return 512;
+    if (K <= 0) return 0;
+    return 512 + (prepare_two_pass(K) ? qt_align_up((size_t)K * K * 4, 256) + 256 : 0);
 }
 
 extern "C" int qt_hessian_prepare(const float* G, int K, int64_t n_samples, float percdamp, const int32_t* perm,
@@ -154,8 +213,9 @@ extern "C" int qt_hessian_prepare(const float* G, int K, int64_t n_samples, floa
                                   qt_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(G && A && dead && K > 0 && n_samples > 0, "qt_hessian_prepare: bad arguments");
-    if (!workspace || workspace_bytes < 512) {
-        qt_set_error("qt_hessian_prepare: workspace %zu < required 512", workspace_bytes);
+    const size_t need = qt_hessian_prepare_workspace_bytes(K);
+    if (!workspace || workspace_bytes < need) {
+        qt_set_error("qt_hessian_prepare: workspace %zu < required %zu", workspace_bytes, need);
         return QT_ERR_WORKSPACE;
     }
     float* stats = (float*)qt_align_up((size_t)workspace, 256);
@@ -163,6 +223,22 @@ extern "C" int qt_hessian_prepare(const float* G, int K, int64_t n_samples, floa
     hipLaunchKernelGGL(diag_stats_kernel, dim3(1), dim3(1024), 0, stream, G, K, c, percdamp, perm, dead, diag_out,
                        stats);
     QT_LAUNCH_CHECK();
+    if (prepare_two_pass(K) && (((uintptr_t)G) & 15) == 0) {
+        float* S = (float*)qt_align_up((size_t)(stats + 64), 256);
+        const int nb = (K + 63) / 64;
+        hipLaunchKernelGGL(symmetrize_to_kernel, dim3(nb, nb), dim3(256), 0, stream, G, K, S);
+        QT_LAUNCH_CHECK();
+        const size_t lds = (size_t)K * 4;
+        static QtOncePerDevice lds_attr;
+        QT_HIP(lds_attr.run([&] {
+            return hipFuncSetAttribute((const void*)build_flipped_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+        }));
+        hipLaunchKernelGGL(build_flipped_rows_kernel, dim3(K), dim3(256), lds, stream, (const float*)S, K, c, perm,
+                           (const uint8_t*)dead, (const float*)stats, A);
+        QT_LAUNCH_CHECK();
+        return QT_OK;
+    }
     hipLaunchKernelGGL(build_flipped_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, G, K, c, perm,
                        (const uint8_t*)dead, (const float*)stats, A);
     QT_LAUNCH_CHECK();

@@ -204,6 +204,34 @@ def test_hessian_prepare(ops, oracle, dev, K, with_perm, with_dead):
     np.testing.assert_allclose(np.diag(got), np.diag(want), rtol=2.4e-7)
 
 
+@pytest.mark.parametrize("K,with_perm,with_dead", [(2048, True, True), (2056, True, False), (4096, False, False),
+                                                   (5120, True, True)])
+def test_hessian_prepare_two_pass_equals_one_pass(ops, dev, monkeypatch, K, with_perm, with_dead):
+    """From K = 2048 the prepared matrix is built in two coalesced passes (symmetric copy, then one row of it in LDS per
+    output row) instead of one kernel that walks down columns of the lower triangle -- pure data movement, so the
+    upper triangle of A (all the factorisation reads), the dead flags and the diagonal are the one-pass kernel's bit
+    for bit; the strict upper part of G (never valid) is poisoned to show that nothing reads it."""
+    torch.manual_seed(K)
+    X = torch.randn(3 * K, K, device=dev)
+    if with_dead:
+        X[:, [5, K - 3, K // 2]] = 0
+    X = X.to(torch.bfloat16)
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    ops.xtx_accumulate(X, G)
+    tri = torch.triu(torch.ones(K, K, dtype=torch.bool, device=dev), 1)
+    blk = (torch.arange(K, device=dev) // 256)
+    G[tri & (blk[:, None] != blk[None, :])] = float("nan")      # outside the lower 256-tiles: garbage in real use
+    perm = torch.randperm(K, device=dev).to(torch.int32) if with_perm else None
+    monkeypatch.setenv("QT_PREPARE_TWO_PASS", "0")
+    A0, dead0, diag0 = ops.hessian_prepare(G, 8, 0.01, perm)
+    monkeypatch.delenv("QT_PREPARE_TWO_PASS")
+    A1, dead1, diag1 = ops.hessian_prepare(G, 8, 0.01, perm)
+    torch.cuda.synchronize()
+    assert torch.equal(dead0, dead1) and torch.equal(diag0, diag1)
+    assert torch.equal(torch.triu(A0), torch.triu(A1))
+    assert bool(torch.isfinite(torch.triu(A1)).all())
+
+
 @pytest.mark.parametrize("K", [1, 7, 1000, 4096, 14336])
 def test_argsort_desc_stable(ops, dev, K):
     g = torch.Generator(device=dev).manual_seed(K)

@@ -9,8 +9,8 @@ cd "$R"
 echo "bench default" && python3 bench.py > "$O/bench_default.json" 2> "$O/bench_default.err" || exit 1
 echo "bench per-sample" && python3 bench.py --accumulate per-sample --no-cpu-baseline > "$O/bench_persample.json" 2>/dev/null || exit 1
 echo "bench awq" && python3 bench.py --method awq --no-cpu-baseline > "$O/bench_awq.json" 2>/dev/null || exit 1
-echo "bench 70b" && python3 bench.py --model llama-3-70b --steps 4 --warmup 1 > "$O/bench_70b.json" 2>/dev/null || exit 1
-echo "bench mixtral" && python3 bench.py --model mixtral-8x7b --steps 4 --warmup 1 > "$O/bench_mixtral.json" 2>/dev/null || exit 1
+echo "bench 70b" && python3 bench.py --model llama-3-70b --steps 4 --warmup 2 > "$O/bench_70b.json" 2>/dev/null || exit 1
+echo "bench mixtral" && python3 bench.py --model mixtral-8x7b --steps 4 --warmup 2 > "$O/bench_mixtral.json" 2>/dev/null || exit 1
 echo "bench 2 ranks (gloo rehearsal, self-launched)" && QT_BENCH_REHEARSE_GLOO=1 python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > "$O/bench_rehearsal_2ranks_one_gpu.json" 2>/dev/null || exit 1
 echo "full model" && python3 tools/full_model.py 32 2>&1 | grep -v "amdgpu.ids\|huggingface\|offline-mode" > "$O/full_model.txt" || exit 1
 echo "stage times" && python3 tools/stage_times.py > "$O/stage_times.txt" 2>&1 || exit 1
