@@ -75,7 +75,8 @@ int qt_act_stats_accumulate(const void* X, int x_dtype, int64_t n_tokens, int K,
                             qt_stream_t stream);
 
 /* ---- a8/a9  dead columns, damping, activation ordering (quantize_weight, gptq.py:86) -------
- * From the Gram sum G (lower triangle) and sample count n builds, in one pass,
+ * From the Gram sum G (lower triangle) and sample count n builds (one pass; from K = 2048 two coalesced passes
+ * through a symmetric copy of G in the workspace, K*K*4 bytes -- the result is the same to the bit)
  *   Hd = P^T (2/n * G) P  with  dead = diag==0 -> 1,  Hd += percdamp*mean(diag) * I
  * and writes A = flat-reversed Hd (A[i][j] = Hd[K-1-i][K-1-j]), upper triangle valid, which is
  * what qt_cholesky_inverse_upper consumes.  perm (int32[K], sweep position -> original column)
