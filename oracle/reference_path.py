@@ -298,10 +298,13 @@ def gptq_sweep_numpy(W, U, scale, zp, g_idx, blocksize=128, num_bits=4):
 # ---------------------------------------------------------------------------------------------
 def quantize_weight(W, H, *, group_size=128, symmetric=True, num_bits=4, blocksize=128,
                     percdamp=0.01, actorder="static", inverse="lapack", U_override=None,
-                    sweep=gptq_sweep_c):
+                    sweep=gptq_sweep_c, perm_override=None):
     """Full per-Linear GPTQ as upstream's ``quantize_weight``.  ``actorder`` in
     {None, "static"/"weight", "group"}.  Returns dict with q (int8, original column order),
-    scale, zp (fp32 [R,G]), g_idx (int32 [K] or None), w_dq, loss, perm, U, ok."""
+    scale, zp (fp32 [R,G]), g_idx (int32 [K] or None), w_dq, loss, perm, U, ok.
+    ``perm_override`` (tests only): sweep in this order instead of ``argsort(diag H)`` -- the argsort of nearly
+    equal diagonal entries flips with the last bit of H, i.e. with the order a Hessian was summed in; fixing the
+    order separates that from everything else (tests/own_hessian_cases.py)."""
     W = np.array(W, dtype=np.float32, copy=True)
     H = np.array(H, dtype=np.float32, copy=True)
     R, K = W.shape
@@ -310,12 +313,12 @@ def quantize_weight(W, H, *, group_size=128, symmetric=True, num_bits=4, blocksi
     perm = None
     if actorder in ("static", "weight"):
         scale, zp = minmax_qparams(W, group_size, symmetric, num_bits)
-        perm = np.argsort(-np.diag(H), kind="stable")
+        perm = np.argsort(-np.diag(H), kind="stable") if perm_override is None else np.asarray(perm_override, np.int64)
         W = W[:, perm]
         H = H[perm][:, perm]
         g_idx = g_idx[perm]
     elif actorder == "group":
-        perm = np.argsort(-np.diag(H), kind="stable")
+        perm = np.argsort(-np.diag(H), kind="stable") if perm_override is None else np.asarray(perm_override, np.int64)
         W = W[:, perm]
         H = H[perm][:, perm]
         scale, zp = minmax_qparams(W, group_size, symmetric, num_bits)
