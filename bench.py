@@ -326,17 +326,49 @@ def cpu_baseline_port():
     }
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process could open, counted WITHOUT loading the HIP runtime (the launcher parent must stay a process
+    that never touched the GPU): KFD topology nodes that have SIMDs, capped by the render nodes this user can open
+    (a container is usually handed a subset of the host's) and by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES.  -1 when the KFD sysfs tree is absent (the caller then asks torch, whose
+    `device_count()` goes through `hipGetDeviceCount`, i.e. loads the runtime but creates no context)."""
+    import glob
+    import re
+
+    props = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not props:
+        return -1
+    n = 0
+    for p in props:
+        try:
+            m = re.search(r"^simd_count\s+(\d+)", Path(p).read_text(), re.M)
+        except OSError:
+            continue
+        n += bool(m and int(m.group(1)) > 0)
+    render = [d for d in glob.glob("/dev/dri/renderD*") if os.access(d, os.R_OK | os.W_OK)]
+    if render:
+        n = min(n, len(render))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this same command as
     child processes, one per device (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
-    rendezvous on 127.0.0.1), and return the worst exit code.  The parent never touches the GPU
-    (`device_count()` does not initialise it) and never re-execs itself.  Refuses when fewer than N
-    GPUs are visible instead of silently running a smaller job."""
+    rendezvous on 127.0.0.1), and return the worst exit code.  The parent never touches the GPU (devices are
+    counted from sysfs, `visible_gpu_count`) and never re-execs itself.  Refuses when fewer than N
+    GPUs are visible instead of silently running a smaller job; a rank whose device does not exist still
+    fails by itself at `set_device`, and takes the others down with it."""
     import socket
     import subprocess
 
     if not REHEARSE:
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
+        if have < 0:
+            have = torch.cuda.device_count()
         if have < n:
             print(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to run a smaller job "
                   f"(QT_BENCH_REHEARSE_GLOO=1 rehearses the N-rank control flow on one GPU)", file=sys.stderr)

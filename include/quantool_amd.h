@@ -127,8 +127,8 @@ int qt_weight_gather_f32(const void* W, int w_dtype, int R, int K, int64_t ldw, 
  * Outputs Qt[K,R] int8 (integer levels, sweep-position major) and loss[R].
  * blocksize must be 128 (upstream default) in this build.  Bit-exact against
  * oracle/gptq_oracle.c:orc_gptq_sweep for identical inputs -- including when the updates of columns
- * far to the right are applied for several blocks in one pass over W (env QT_SWEEP_BATCH, 1..4 blocks,
- * default 4: every block's product is still its own ascending-k chain, subtracted in block order). */
+ * far to the right are applied for several blocks in one pass over W (env QT_SWEEP_BATCH, 1..8 blocks,
+ * default 4, 8 from K = 8192: every block's product is still its own ascending-k chain, subtracted in block order). */
 size_t qt_gptq_sweep_workspace_bytes(int R, int K, int blocksize);
 int qt_gptq_sweep(float* W, int R, int K, const float* U, const float* scale_t, const float* zp_t,
                   int G, const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt,

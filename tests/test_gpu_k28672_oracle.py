@@ -1,0 +1,128 @@
+"""K = 28672 -- Llama-3-70B's down_proj, the largest Linear group of BASELINE configs[3] and the longest bf16x3 chain the
+library runs (224 panels, 9.9 GB of plane copies) -- against fp64 and against the oracle.
+
+Upstream step: ``quantize_weight``, reached through
+``/root/reference/src/quantool/methods/llm_compressor/gptq/gptq.py:86`` -> ``base.py:161``.
+
+  * factor: fp64 random-probe residual  || U^T U Hd v - v || / || v ||  (the 2e-2 bar of
+    ``test_gpu_fullsize_properties.test_factor_full_size_residual``), the default path (bf16x3 block-row products)
+    against the f32-MFMA chain (``QT_CHOL_G3=0``) element by element, and both against fp64 on a leading block that a
+    host factorisation can afford (the trailing 2048 x 2048 block of U depends on the trailing block of Hd alone);
+  * sweep: a 64-row slice swept by the GPU and by ``oracle.gptq_sweep_c`` given the GPU's U: scales, integer levels,
+    packed words and dequantised weights bit-exact (64 x 28672^2 = 53 GFLOP of C sweep: seconds).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+K = 28672
+N_TOKENS = 32768          # >= K: a full-rank Gram sum (the 70B job has 196 608)
+
+
+@pytest.fixture(scope="module")
+def big(dev):
+    from quantool_amd.hip import ops
+
+    for v in ("QT_CHOL_G3", "QT_CHOL_G3_MIN_CHUNKS"):
+        assert v not in os.environ, f"{v} is set: this test pins the DEFAULT factorisation path"
+    g = torch.Generator(device=dev).manual_seed(2867)
+    gain = torch.ones(K, device=dev)
+    gain[torch.randperm(K, generator=g, device=dev)[: K // 100]] = 10.0
+    G = torch.zeros((K, K), dtype=torch.float32, device=dev)
+    for t0 in range(0, N_TOKENS, 8192):
+        X = (torch.randn((8192, K), generator=g, device=dev) * gain).to(torch.bfloat16)
+        ops.xtx_accumulate(X, G)
+    del X
+    n_samples = N_TOKENS // 512
+    A, dead, _ = ops.hessian_prepare(G, n_samples, 0.01, None)
+    assert not bool(dead.any())
+    Hd = torch.flip(torch.triu(A) + torch.triu(A, 1).t(), dims=(0, 1)).contiguous()     # the damped Hessian, fp32
+    U, info = ops.cholesky_inverse_upper(A)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    return dict(G=G, Hd=Hd, U=U, n=n_samples, gen=g)
+
+
+def test_factor_residual_fp64_probe(big, dev):
+    U, Hd = big["U"], big["Hd"]
+    assert bool((torch.diag(U) > 0).all()) and bool(torch.isfinite(torch.diag(U)).all())
+    v = torch.randn(K, 4, device=dev, dtype=torch.float64)
+
+    def mv(M, x, transpose=False):      # fp64 product with an fp32 matrix, 2048 rows (0.5 GB of fp64) at a time
+        out = torch.zeros_like(x) if transpose else torch.empty_like(x)
+        for r0 in range(0, K, 2048):
+            blk = M[r0:r0 + 2048].double()
+            if transpose:
+                out += blk.t() @ x[r0:r0 + 2048]
+            else:
+                out[r0:r0 + 2048] = blk @ x
+        return out
+
+    r = mv(U, mv(U, mv(Hd, v)), transpose=True) - v
+    res = float(r.norm() / v.norm())
+    print(f"\n[K=28672] || U^T U Hd v - v || / || v || = {res:.3e} (max {float(r.abs().max() / v.abs().max()):.3e})")
+    assert res < 2e-2
+    # strict lower triangle zero-filled (sampled rows: a full tril of 3.3 GB is not needed)
+    for i in (1, 127, 128, 4097, K - 1):
+        assert bool((U[i, :i] == 0).all())
+
+
+def test_default_path_vs_f32_chain_and_fp64_on_the_trailing_block(big, dev, oracle, monkeypatch):
+    from quantool_amd.hip import ops
+
+    U = big["U"]
+    monkeypatch.setenv("QT_CHOL_G3", "0")
+    A0, _, _ = ops.hessian_prepare(big["G"], big["n"], 0.01, None)
+    U0, info0 = ops.cholesky_inverse_upper(A0)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("QT_CHOL_G3")
+    assert int(info0.item()) == 0
+    umax = float(U.abs().max())
+    d = 0.0
+    for r0 in range(0, K, 4096):
+        d = max(d, float((U[r0:r0 + 4096] - U0[r0:r0 + 4096]).abs().max()))
+    rel = d / umax
+    assert not torch.equal(U[:512], U0[:512]), "the default path did not take the bf16x3 products"
+    # U = chol(Hd^-1, upper): its trailing m x m block is chol((Hd^-1)[-m:, -m:]) ... which needs the whole inverse; but
+    # U^-1 = Ut (upper, Hd = Ut Ut^T) has trailing block chol-like of Hd's trailing block ALONE: Hd[-m:, -m:] = Ut_mm Ut_mm^T,
+    # so U[-m:, -m:] = Ut_mm^-1 is a function of Hd[-m:, -m:] only -- a host fp64 factorisation of 2048 x 2048 pins it
+    m = 2048
+    Hb = big["Hd"][-m:, -m:].double().cpu().numpy()
+    J = np.arange(m)[::-1]
+    R = np.linalg.cholesky(Hb[J][:, J]).T                    # flip(Hb) = R^T R
+    truth = np.linalg.inv(R).T[J][:, J]                       # flip(R^-T)
+    e_def = float(np.abs(U[-m:, -m:].cpu().numpy() - truth).max() / np.abs(truth).max())
+    e_f32 = float(np.abs(U0[-m:, -m:].cpu().numpy() - truth).max() / np.abs(truth).max())
+    print(f"\n[K=28672] default (bf16x3) vs f32 chain: max |dU| / max|U| = {rel:.3e}; trailing {m} block vs fp64: "
+          f"default {e_def:.3e}, f32 chain {e_f32:.3e}")
+    assert rel <= 5e-6, rel
+    assert e_def <= 5e-6 and e_f32 <= 5e-6, (e_def, e_f32)
+
+
+def test_64_row_slice_bit_exact_against_the_oracle_given_u(big, dev, oracle):
+    from quantool_amd.hip import ops
+
+    R = 64
+    W = (torch.randn((R, K), generator=big["gen"], device=dev) * 0.02).to(torch.bfloat16)
+    scale, zp, st, zt = ops.group_minmax_qparams(W, 128, True, 4)
+    g_idx = (torch.arange(K, device=dev) // 128).to(torch.int32)
+    Wf = ops.weight_gather_f32(W, None, None)
+    Qt, loss = ops.gptq_sweep(Wf, big["U"], st, zt, g_idx, 128, 4)
+    packed = ops.pack_int4(Qt, None)
+    torch.cuda.synchronize()
+    Wn = W.float().cpu().numpy()
+    s_o, z_o = oracle.minmax_qparams(Wn, 128, True, 4)
+    np.testing.assert_array_equal(scale.cpu().numpy(), s_o)
+    np.testing.assert_array_equal(zp.cpu().numpy(), z_o)
+    Uh = big["U"].cpu().numpy()
+    Q_o, Wdq_o, loss_o = oracle.gptq_sweep_c(Wn, Uh, s_o, z_o, g_idx.cpu().numpy(), 128, 4)
+    del Uh
+    np.testing.assert_array_equal(Qt.t().cpu().numpy(), Q_o)
+    np.testing.assert_array_equal(packed.cpu().numpy(), oracle.pack_int4(Q_o))
+    np.testing.assert_array_equal(Wf.cpu().numpy(), Wdq_o)            # the sweep leaves the dequantised values in W
+    np.testing.assert_allclose(loss.cpu().numpy(), loss_o, rtol=1e-4)
+    assert len(np.unique(Q_o)) >= 14                                  # a real sweep, not a degenerate one
