@@ -44,6 +44,7 @@ class HessianAccumulator:
             stage_tokens = max(4096, min(65536, self.STAGE_BYTES // (2 * K)))
         self.stage_tokens = int(stage_tokens) // 64 * 64
         self._stage: Optional[torch.Tensor] = None
+        self._stage_sized = False   # the fp32 path halves stage_tokens exactly once
         self._fill = 0
 
     @property
@@ -62,25 +63,30 @@ class HessianAccumulator:
             num_samples = X.shape[0] if X.dim() == 3 else 1
         X2 = X.reshape(-1, self.K)
         t = X2.shape[0]
-        self.n += int(num_samples)
-        if t == 0:
-            return
         if X2.dtype not in (torch.bfloat16, torch.float16):
-            mode = ops.wide_gram_mode()
-            if mode == "exact":
-                # an fp32 checkpoint: upstream accumulates inp.float(), i.e. an fp32 Gram product -- staged and
-                # accumulated in fp32 through the three-plane product (ops.xtx_accumulate_f32)
+            # an fp32 checkpoint: upstream accumulates inp.float(), i.e. an fp32 Gram product -- staged and accumulated
+            # in fp32 through the three-plane product (ops.xtx_accumulate_f32) when this accumulator is (or can still
+            # become) an fp32 one.  Anything else rounds the batch to the accumulator's 16-bit dtype, and that is never
+            # silent: also a wide batch arriving AFTER 16-bit ones goes through the policy (logged once, or refused).
+            if ops.wide_gram_mode() == "exact" and self.dtype in (None, torch.float32):
                 if X2.dtype != torch.float32:
                     X2 = X2.float()
-                if self.dtype is None:
-                    self.dtype = torch.float32
+                self.dtype = torch.float32
             else:
-                ops.wide_activation_policy(X2.dtype)      # rounded to bf16, loudly (or refused)
+                ops.wide_activation_policy(X2.dtype)
+        self.n += int(num_samples)      # after the policy: a refused batch is not counted
+        if t == 0:
+            return
         if self.dtype is None:
             # the checkpoint's own dtype (the reference injects none, base.py:222-241); see ops.as_act16
             self.dtype = X2.dtype if X2.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
-        if self.dtype == torch.float32 and self.stage_tokens > 0 and self._stage is None:
-            self.stage_tokens = max(128, self.stage_tokens // 2 // 128 * 128)     # same bytes of staging at 4 B / element
+        if self.dtype == torch.float32 and not self._stage_sized:
+            # same bytes of staging at 4 B / element -- ONCE per accumulator (halving on every direct batch, or after
+            # every release_stage(), would walk the buffer down to 128 rows and turn every short batch into its own
+            # read-modify-write of G)
+            self._stage_sized = True
+            if self.stage_tokens > 0:
+                self.stage_tokens = max(128, self.stage_tokens // 2 // 128 * 128)
         if self.stage_tokens <= 0 or t >= min(self.DIRECT_TOKENS, self.stage_tokens):
             self._gram(X2 if X2.dtype == self.dtype else X2.to(self.dtype))
             return
@@ -190,8 +196,9 @@ def gptq_quantize_shared(weights: Sequence[torch.Tensor], acc: HessianAccumulato
     g_orig = (ar // gsz).to(torch.int32)
 
     # ---- prepare + factorise once for all sharers (a8) -----------------------------------
-    A, dead, _ = ops.hessian_prepare(acc.G, acc.n, dampening_frac, perm)
-    U, info = ops.cholesky_inverse_upper(A)
+    ubuf = ops.factor_buffer(K, dev)        # U's storage doubles as prepare's scratch (no K x K workspace kept per stream)
+    A, dead, _ = ops.hessian_prepare(acc.G, acc.n, dampening_frac, perm, scratch=ubuf)
+    U, info = ops.cholesky_inverse_upper(A, U_out=ops.factor_view(ubuf, K))
     del A
 
     # ---- stacked fp32 working copy in sweep order, observer (a10) ------------------------

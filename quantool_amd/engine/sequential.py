@@ -93,58 +93,114 @@ class _UnfusedExperts(nn.Module):
     def forward(self, hidden_states, top_k_index, top_k_weights):
         out = torch.zeros_like(hidden_states)
         mask = torch.nn.functional.one_hot(top_k_index, num_classes=self.num_experts).permute(2, 1, 0)
-        batch, per = _CALIB_CTX["samples"], _CALIB_CTX["tokens_per_sample"]
-        for e in torch.greater(mask.sum(dim=(-1, -2)), 0).nonzero().flatten().tolist():
-            pos, tok = torch.where(mask[e])
-            if batch > 1 and per:
-                # samples (of this forward) that routed at least one token here: what one forward per sample would count
-                _CALIB_CTX["samples"] = int(torch.unique(torch.div(tok, per, rounding_mode="floor")).numel())
-            gate, up = self.experts[e].gate_up_proj(hidden_states[tok]).chunk(2, dim=-1)
-            y = self.experts[e].down_proj(self.act_fn(gate) * up) * top_k_weights[tok, pos, None]
-            out.index_add_(0, tok, y.to(out.dtype))
-        _CALIB_CTX["samples"] = batch
+        ctx = _CALIB_CTX
+        batch, per = ctx["samples"], ctx["tokens_per_sample"]
+        routed = mask.sum(dim=1) > 0                                  # [experts, tokens]
+        n_tok = int(routed.shape[1])
+        if batch > 1 and per:
+            # per expert, the samples (of this forward) that routed at least one token to it -- what one forward per
+            # sample would count -- for ALL experts in one device op and one host read (it was a torch.unique and a
+            # host synchronisation per expert per forward)
+            sid = torch.div(torch.arange(n_tok, device=routed.device), per, rounding_mode="floor")
+            per_sample = torch.zeros((self.num_experts, (n_tok + per - 1) // per), dtype=torch.float32, device=routed.device)
+            per_sample.index_add_(1, sid, routed.to(torch.float32))
+            counts = (per_sample > 0).sum(dim=1).tolist()
+        else:
+            counts = [batch if hit else 0 for hit in routed.any(dim=1).tolist()]
+        try:
+            for e, n_samples in enumerate(counts):
+                if n_samples == 0:
+                    continue
+                pos, tok = torch.where(mask[e])
+                ctx["samples"] = int(n_samples)
+                gate, up = self.experts[e].gate_up_proj(hidden_states[tok]).chunk(2, dim=-1)
+                y = self.experts[e].down_proj(self.act_fn(gate) * up) * top_k_weights[tok, pos, None]
+                out.index_add_(0, tok, y.to(out.dtype))
+        finally:
+            ctx["samples"] = batch       # also when an expert raised: the next layer / model starts from the forward's count
         return out
 
 
-def expert_bank_checkpoint_names(state: Dict[str, torch.Tensor], banks: Dict[str, "_UnfusedExperts"]) -> Dict[str, torch.Tensor]:
+#: Per-expert checkpoint vocabulary by ``config.model_type``: (name of the MoE block in the per-expert layout or None to
+#: keep the module's own, leaf names of the gate / up / down Linears).  Mixtral's per-expert checkpoints -- the layout
+#: transformers' own loader converts FROM (``transformers/conversion_mapping.py``, entry "mixtral":
+#: ``.block_sparse_moe.`` -> ``.mlp.``, ``.experts.*.w1.weight`` + ``.experts.*.w3.weight`` -> ``.experts.gate_up_proj``,
+#: ``.experts.*.w2.weight`` -> ``.experts.down_proj``) -- say ``block_sparse_moe.experts.{e}.w1 / w3 / w2``; the
+#: Qwen-MoE family (and the default) says ``mlp.experts.{e}.gate_proj / up_proj / down_proj``.
+EXPERT_LAYOUTS = {
+    "mixtral": ("block_sparse_moe", {"gate_proj": "w1", "up_proj": "w3", "down_proj": "w2"}),
+    None: (None, {"gate_proj": "gate_proj", "up_proj": "up_proj", "down_proj": "down_proj"}),
+}
+
+
+def expert_layout(model_type):
+    return EXPERT_LAYOUTS.get(model_type, EXPERT_LAYOUTS[None])
+
+
+def expert_bank_module_renames(banks, model_type=None) -> Dict[str, str]:
+    """{module-name prefix as the model has it: prefix as the checkpoint says it} for the MoE blocks that hold an
+    unfused bank -- applied to tensor names AND to the module names inside ``quantization_config`` (``ignore``)."""
+    block, _ = expert_layout(model_type)
+    out = {}
+    for bank in banks:
+        parent, _, leaf = bank.rpartition(".")
+        if block and parent and parent.rpartition(".")[2] != block:
+            out[parent] = parent.rpartition(".")[0] + ("." if "." in parent else "") + block
+    return out
+
+
+def rename_module_prefix(name: str, renames: Dict[str, str]) -> str:
+    for old, new in renames.items():
+        if name == old or name.startswith(old + "."):
+            return new + name[len(old):]
+    return name
+
+
+def expert_bank_checkpoint_names(state: Dict[str, torch.Tensor], banks: Dict[str, "_UnfusedExperts"],
+                                 model_type=None) -> Dict[str, torch.Tensor]:
     """Checkpoint names for what ``_UnfusedExperts`` holds (it exists for calibration only; no loader knows
     its ``<bank>.experts.{e}.gate_up_proj`` modules).
 
     Written instead, per expert ``e`` of bank ``<bank>`` (e.g. ``model.layers.3.mlp.experts``) -- the per-expert
-    Linear layout MoE checkpoints and their loaders use (Mixtral's ``experts.{e}.w1/w3/w2``, Qwen-MoE's
-    ``experts.{e}.gate_proj/up_proj/down_proj``), which a compressed-tensors ``Linear`` target can address:
+    Linear layout MoE checkpoints and their loaders use, which a compressed-tensors ``Linear`` target can address,
+    in the vocabulary of the architecture (``EXPERT_LAYOUTS``: Mixtral ``block_sparse_moe.experts.{e}.w1 / w3 / w2``,
+    otherwise ``experts.{e}.gate_proj / up_proj / down_proj``):
 
-      ``<bank>.{e}.gate_proj.*`` / ``<bank>.{e}.up_proj.*``  rows ``[0, I)`` / ``[I, 2I)`` of the fused gate_up matrix:
+      ``<bank>.{e}.<gate>.*`` / ``<bank>.{e}.<up>.*``  rows ``[0, I)`` / ``[I, 2I)`` of the fused gate_up matrix:
                                  GPTQ rows are independent given the factor, so packed words, scales, zero-points
                                  split by rows exactly; ``weight_g_idx`` (per input column) is shared; ``weight_shape``
                                  becomes ``[I, H]``
-      ``<bank>.{e}.down_proj.*``  unchanged
+      ``<bank>.{e}.<down>.*``     unchanged
 
     Dense (un-quantised or ``save_compressed=False``) expert weights are split the same way into
-    ``....gate_proj.weight`` / ``up_proj.weight`` / ``down_proj.weight``.  INTEGRATION.md section 4 documents it."""
+    ``....<gate>.weight`` / ``<up>.weight`` / ``<down>.weight``.  INTEGRATION.md section 5 documents it."""
+    _, leafs = expert_layout(model_type)
+    renames = expert_bank_module_renames(banks, model_type)
     out: Dict[str, torch.Tensor] = {}
     for name, t in state.items():
         bank = next((b for b in banks if name.startswith(b + ".experts.")), None)
         if bank is None:
-            out[name] = t
+            out[rename_module_prefix(name, renames)] = t
             continue
         e, proj, leaf = name[len(bank) + len(".experts."):].split(".", 2)
+        cbank = rename_module_prefix(bank, renames)
         if proj != "gate_up_proj":
-            out[f"{bank}.{e}.{proj}.{leaf}"] = t
+            out[f"{cbank}.{e}.{leafs.get(proj, proj)}.{leaf}"] = t
             continue
+        gate, up = f"{cbank}.{e}.{leafs['gate_proj']}", f"{cbank}.{e}.{leafs['up_proj']}"
         if leaf == "weight_g_idx":                      # per input column: both halves read the same columns
-            out[f"{bank}.{e}.gate_proj.{leaf}"] = t
-            out[f"{bank}.{e}.up_proj.{leaf}"] = t.clone()          # safetensors refuses tensors that share storage
+            out[f"{gate}.{leaf}"] = t
+            out[f"{up}.{leaf}"] = t.clone()          # safetensors refuses tensors that share storage
         elif leaf == "weight_shape":
             half = torch.tensor([int(t[0]) // 2, int(t[1])], dtype=t.dtype)
-            out[f"{bank}.{e}.gate_proj.{leaf}"] = half
-            out[f"{bank}.{e}.up_proj.{leaf}"] = half.clone()
+            out[f"{gate}.{leaf}"] = half
+            out[f"{up}.{leaf}"] = half.clone()
         else:                                           # row-indexed: weight, weight_packed, weight_scale, weight_zero_point
             if t.shape[0] % 2:
                 raise ValueError(f"{name}: {t.shape[0]} rows cannot be split into gate and up halves")
             inter = t.shape[0] // 2
-            out[f"{bank}.{e}.gate_proj.{leaf}"] = t[:inter].contiguous()
-            out[f"{bank}.{e}.up_proj.{leaf}"] = t[inter:].contiguous()
+            out[f"{gate}.{leaf}"] = t[:inter].contiguous()
+            out[f"{up}.{leaf}"] = t[inter:].contiguous()
     return out
 
 
@@ -264,11 +320,16 @@ def _save_compressed(model: nn.Module, save_directory, save_compressed: bool = T
         for mod, r in results.items():
             for k, v in result_tensors(r).items():
                 state[f"{mod}.{k}"] = v
-    if banks:
-        state = expert_bank_checkpoint_names(state, banks)
     base_cfg = model.config.to_dict() if hasattr(model, "config") and hasattr(model.config, "to_dict") else {}
+    ignore = list(meta.get("ignore", []))
+    if banks:
+        model_type = base_cfg.get("model_type")
+        state = expert_bank_checkpoint_names(state, banks, model_type)
+        # module names inside the saved quantization_config follow the tensors: same pass, same table
+        renames = expert_bank_module_renames(banks, model_type)
+        ignore = [rename_module_prefix(n, renames) for n in ignore]
     save_state(state, quantization_config(meta.get("weights", {}), meta.get("format", "pack-quantized"),
-                                          meta.get("ignore", []), meta.get("input_activations")), save_directory, base_cfg,
+                                          ignore, meta.get("input_activations")), save_directory, base_cfg,
                max_shard_size=max_shard_size)
 
 

@@ -8,6 +8,11 @@ Every Linear group's {X^T X, factorisation, sweep, pack} is independent given it
 units are assigned to ranks up front (LPT-greedy on a K^2*(N+R) cost) and processed with no
 data-path collective.  The only exchange is the gather of the packed state to rank 0 at the end
 (RCCL on GPUs: backend "nccl"; gloo in the CPU tests).  One process per GPU.
+
+State of the evidence: the driver has had no 8-GPU node so far, so every collective below has run over gloo (CPU
+tests, and two ranks sharing one GPU) and never over RCCL.  They are written so that no rank can leave a collective
+the others enter: nothing rank-local is validated before a collective, error conditions travel inside the exchanged
+buffers and are raised by every rank alike afterwards.
 """
 from __future__ import annotations
 
@@ -71,28 +76,42 @@ def _unflatten(flat: torch.Tensor, meta: list) -> Dict[str, torch.Tensor]:
 def gather_state_dict(local: Dict[str, torch.Tensor], dst: int = 0, group=None, device=None):
     """Gather every rank's {name: tensor} to ``dst``.  Returns the merged dict on ``dst``, None
     elsewhere.  One flat byte buffer per rank: one large transfer per peer (xGMI links are
-    point-to-point, so few large messages beat many small ones)."""
+    point-to-point, so few large messages beat many small ones).
+
+    No object collective: a rank's buffer is its tensors (16-byte aligned) followed by their table of contents
+    (names, dtypes, shapes, offsets as UTF-8 JSON), and the only thing exchanged beforehand is a fixed-layout
+    ``int64[2]`` per rank (payload bytes, table bytes) in ONE tensor all-gather -- on RCCL a device collective like
+    the transfers themselves, with no pickling and no host round trip through a store."""
+    import json
+
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     flat, meta = _flatten(local, device)
-    metas = [None] * world
-    dist.all_gather_object(metas, (meta, int(flat.numel())), group=group)
+    toc = torch.frombuffer(bytearray(json.dumps(meta).encode("utf-8")), dtype=torch.uint8).to(flat.device)
+    payload = int(flat.numel())
+    sizes = _comm(torch.tensor([payload, int(toc.numel())], dtype=torch.int64, device=flat.device), group)
+    all_sizes = [torch.empty_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = [tuple(int(v) for v in t.tolist()) for t in all_sizes]
     # Posted as ONE batch so that RCCL runs the transfers as a group: the receives on ``dst`` then
     # progress concurrently, one per xGMI link, instead of one after the other.
     if rank == dst:
         merged = dict(_unflatten(flat, meta))
-        bufs = {r: torch.empty(metas[r][1], dtype=torch.uint8, device=flat.device)
-                for r in range(world) if r != dst and metas[r][1] > 0}
+        bufs = {r: torch.empty(sum(all_sizes[r]), dtype=torch.uint8, device=flat.device)
+                for r in range(world) if r != dst and all_sizes[r][0] > 0}
         if bufs:
             for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, r, group) for r, buf in bufs.items()]):
                 q.wait()
         for r, buf in bufs.items():
-            merged.update(_unflatten(buf, metas[r][0]))
+            n_pay, n_toc = all_sizes[r]
+            meta_r = [(n, d, tuple(sh), o, b) for n, d, sh, o, b in
+                      json.loads(bytes(buf[n_pay:n_pay + n_toc].cpu().tolist()).decode("utf-8"))]
+            merged.update(_unflatten(buf, meta_r))
         return merged
-    if flat.numel():
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, dst, group)]):
+    if payload:
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, torch.cat([flat, toc]), dst, group)]):
             q.wait()
     return None
 
@@ -118,10 +137,14 @@ def allreduce_gram(G: torch.Tensor, n_samples: int, group=None):
 
     K = G.shape[0]
     bands = list(_lower_block_rows(K))
-    if not 0 <= int(n_samples) < (1 << 24) // max(1, dist.get_world_size(group)):
-        raise ValueError(f"sample count {n_samples} does not travel exactly as fp32 next to the Gram bands")
-    # the sample count rides at the end of the same buffer (integers < 2^24 add exactly in fp32)
-    count = torch.tensor([float(int(n_samples))], dtype=G.dtype, device=G.device)
+    # The sample count rides at the end of the same buffer as two 12-bit halves (sums of world <= 4096 such halves
+    # are exact in fp32) plus a "my count does not fit" flag.  Nothing is validated BEFORE the collective: the counts
+    # differ per rank, and a rank that raised on its own value would leave the others waiting in the all-reduce until
+    # the RCCL timeout.  Every rank sees the same reduced words and raises (or not) together afterwards.
+    n_local = int(n_samples)
+    fits = 0 <= n_local < (1 << 24)
+    words = [float(n_local & 0xFFF), float(n_local >> 12), 0.0] if fits else [0.0, 0.0, 1.0]
+    count = torch.tensor(words, dtype=G.dtype, device=G.device)
     flat = torch.cat([G[rows, :cols].reshape(-1) for rows, cols in bands] + [count])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
@@ -129,7 +152,10 @@ def allreduce_gram(G: torch.Tensor, n_samples: int, group=None):
         cnt = (rows.stop - rows.start) * cols
         G[rows, :cols] = flat[off:off + cnt].view(rows.stop - rows.start, cols)
         off += cnt
-    return int(round(float(flat[off].item())))
+    lo, hi, bad = (int(round(v)) for v in flat[off:off + 3].tolist())
+    if bad:
+        raise ValueError(f"{bad} rank(s) hold a sample count outside [0, 2^24): it does not travel next to the Gram bands")
+    return (hi << 12) + lo
 
 
 # ---- partitioning B: one Linear group spread over the ranks ------------------------
@@ -270,9 +296,14 @@ def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, grou
             n += sum(_pad16(rows * c * torch.empty(0, dtype=dt).element_size()) for _, c, dt in cols)
         return n
 
-    width = max(rank_bytes(r) for r in range(world))
+    # 16-byte header per rank: byte 0 = "my outputs do not have the layout every rank assumes".  A mismatch is not
+    # raised before the collective (only ranks that swept rows can see it; the others would wait in the all-gather):
+    # it travels in the buffer and every rank raises the same error afterwards.
+    HDR = 16
+    width = HDR + max(rank_bytes(r) for r in range(world))
     send = torch.zeros(width, dtype=torch.uint8, device=dev)
-    off = 0
+    off = HDR
+    layout_error = None
     g_idx_local = None
     results = []
     for (b, e), cols in zip(mine, schema):
@@ -283,9 +314,10 @@ def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, grou
             if r is not None:
                 t = r.dequantized(dt) if key == "@dequantized" else getattr(r, key)
                 if t is None or tuple(t.shape) != (e - b, c) or t.dtype != dt:
-                    raise RuntimeError(f"row-split gather: {key} is {None if t is None else (tuple(t.shape), t.dtype)}, "
-                                       f"the layout every rank assumes says {((e - b, c), dt)}")
-                send[off:off + nbytes] = t.contiguous().reshape(-1).view(torch.uint8)
+                    layout_error = layout_error or (f"{key} is {None if t is None else (tuple(t.shape), t.dtype)}, "
+                                                    f"the layout every rank assumes says {((e - b, c), dt)}")
+                else:
+                    send[off:off + nbytes] = t.contiguous().reshape(-1).view(torch.uint8)
             off += _pad16(nbytes)
         if r is not None and with_gidx and g_idx_local is None:
             g_idx_local = r.weight_g_idx
@@ -293,12 +325,18 @@ def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, grou
         if g_idx_local is not None:
             send[off:off + 4 * K] = g_idx_local.to(torch.int32).contiguous().view(torch.uint8)
         off += _pad16(4 * K)
+    if layout_error is not None:
+        send[0] = 1
     send = _comm(send, group)
     bufs = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(bufs, send, group=group)
     bufs = [buf.to(dev) for buf in bufs]
+    failed = [r for r in range(world) if int(bufs[r][0].item()) != 0]
+    if failed:
+        raise RuntimeError(f"row-split gather: rank(s) {failed} produced outputs whose layout differs from the one every "
+                           f"rank derives from the arguments" + (f" (here: {layout_error})" if layout_error else ""))
 
-    offs = [0] * world
+    offs = [HDR] * world
     out = []
     for w, sl, cols in zip(weights, slices, schema):
         R = int(w.shape[0])

@@ -209,9 +209,23 @@ def argsort_desc(values: torch.Tensor):
     return perm, inv
 
 
+def factor_buffer(K: int, device) -> torch.Tensor:
+    """Flat fp32 buffer that holds the factor U ([K, K], its first K*K elements: ``factor_view``) and, before U is
+    written, serves ``hessian_prepare`` as scratch (``scratch=``): the two-pass prepare needs a K x K symmetric copy
+    of G -- 0.8 GB at K = 14336, 3.3 GB at K = 28672 -- which would otherwise sit in a grow-only per-stream workspace
+    for the life of the process next to the factor it precedes."""
+    return torch.empty(K * K + 256, dtype=torch.float32, device=device)
+
+
+def factor_view(buf: torch.Tensor, K: int) -> torch.Tensor:
+    return buf[:K * K].view(K, K)
+
+
 def hessian_prepare(G: torch.Tensor, n_samples: int, percdamp: float, perm: Optional[torch.Tensor] = None,
-                    A_out: Optional[torch.Tensor] = None):
-    """Returns (A flipped+damped [K,K] fp32 upper-valid, dead uint8[K], diag fp32[K])."""
+                    A_out: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None):
+    """Returns (A flipped+damped [K,K] fp32 upper-valid, dead uint8[K], diag fp32[K]).  ``scratch``: a contiguous
+    device tensor whose bytes may be used as the workspace (e.g. ``factor_buffer``: the buffer the factor will be
+    written to afterwards); too small or absent: the cached per-stream workspace."""
     lib = load()
     _req(G, torch.float32, "G", 2)
     K = G.shape[0]
@@ -227,7 +241,11 @@ def hessian_prepare(G: torch.Tensor, n_samples: int, percdamp: float, perm: Opti
         raise ValueError("A must be contiguous [K, K]")
     dead = torch.empty(K, dtype=torch.uint8, device=G.device)
     diag = torch.empty(K, dtype=torch.float32, device=G.device)
-    ws = workspace(lib.qt_hessian_prepare_workspace_bytes(K), G.device, "prep")
+    need = lib.qt_hessian_prepare_workspace_bytes(K)
+    if scratch is not None and scratch.is_cuda and scratch.is_contiguous() and scratch.numel() * scratch.element_size() >= need:
+        ws = scratch.view(torch.uint8).reshape(-1)
+    else:
+        ws = workspace(need, G.device, "prep")
     check("qt_hessian_prepare", lib.qt_hessian_prepare(G.data_ptr(), K, int(n_samples), float(percdamp), _ptr(perm),
                                                        A.data_ptr(), dead.data_ptr(), diag.data_ptr(), ws.data_ptr(),
                                                        ws.numel(), _stream()))

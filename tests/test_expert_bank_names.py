@@ -118,3 +118,56 @@ def test_result_store_releases_detail_beyond_its_budget(monkeypatch):
 
     with pytest.raises(RuntimeError, match="released"):
         store["c"].dequantized()
+
+
+def test_mixtral_vocabulary_matches_what_transformers_converts_from(tmp_path):
+    """``config.model_type == "mixtral"``: the per-expert names are the legacy Mixtral checkpoint's
+    (``block_sparse_moe.experts.{e}.w1 / w3 / w2``), checked against the source patterns of the installed transformers'
+    own conversion table for that architecture; ``ignore`` entries of the saved quantization_config are renamed in the
+    same pass."""
+    import json
+    import re
+
+    m = nn.Module()
+    m.model = nn.Module()
+    blk = nn.Module()
+    blk.mlp = nn.Module()
+    blk.mlp.experts = FusedExperts()
+    blk.mlp.gate = nn.Linear(H, E, bias=False)
+    blk.self_attn = nn.Linear(H, H, bias=False)
+    m.model.layers = nn.ModuleList([blk])
+    m.config = types.SimpleNamespace(to_dict=lambda: {"model_type": "mixtral", "architectures": ["MixtralForCausalLM"]})
+    assert sq.unfuse_expert_banks(m) == 1
+    res = {}
+    for e in range(E):
+        res[f"model.layers.0.mlp.experts.experts.{e}.gate_up_proj"] = Res(2 * I, H)
+        res[f"model.layers.0.mlp.experts.experts.{e}.down_proj"] = Res(H, I)
+    m._qt_results = res
+    m._qt_meta = {"weights": {"num_bits": 4}, "format": "pack-quantized", "ignore": ["lm_head", "model.layers.0.mlp.gate"]}
+    sq._save_compressed(m, str(tmp_path))
+    sd = load_state(str(tmp_path))
+    p = "model.layers.0.block_sparse_moe"
+    for e in range(E):
+        r = res[f"model.layers.0.mlp.experts.experts.{e}.gate_up_proj"]
+        assert torch.equal(sd[f"{p}.experts.{e}.w1.weight_packed"], r.weight_packed[:I])
+        assert torch.equal(sd[f"{p}.experts.{e}.w3.weight_packed"], r.weight_packed[I:])
+        assert torch.equal(sd[f"{p}.experts.{e}.w2.weight_packed"],
+                           res[f"model.layers.0.mlp.experts.experts.{e}.down_proj"].weight_packed)
+    assert f"{p}.gate.weight" in sd and "model.layers.0.self_attn.weight" in sd
+    assert not any(".mlp." in k or "gate_proj" in k or "up_proj" in k for k in sd), sorted(sd)
+    cfg = json.loads((tmp_path / "config.json").read_text())
+    assert cfg["quantization_config"]["ignore"] == ["lm_head", "model.layers.0.block_sparse_moe.gate"]
+    # the installed transformers converts FROM exactly these names (source patterns of its "mixtral" entry)
+    conv = __import__("pytest").importorskip("transformers.conversion_mapping")
+    table = getattr(conv, "_build_checkpoint_conversion_mapping", None)
+    if table is None:
+        return
+    pats = []
+    for entry in table().get("mixtral", []):
+        src = getattr(entry, "source_patterns", None)
+        pats += [src] if isinstance(src, str) else list(src or [])
+    assert any("block_sparse_moe" in q for q in pats)
+    for leaf in ("w1", "w2", "w3"):
+        assert f".experts.*.{leaf}.weight" in pats                                   # what the loader collects per expert ...
+        rx = re.compile(rf"\.block_sparse_moe\.experts\.\d+\.{leaf}\.weight_packed$")        # ... and what was written
+        assert sum(bool(rx.search(k)) for k in sd) == E, sorted(sd)[:6]

@@ -58,6 +58,19 @@ def _worker(rank, world, port, q):
         assert torch.allclose(part[:256, :256], full[:256, :256]) and torch.allclose(part[256:], full[256:])
         # ... and nothing else travels: the block above the diagonal tiles keeps the local partial
         assert torch.equal(part[:256, 256:], mine_only[:256, 256:])
+        # counts beyond 12 bits travel as two halves; a count that does not fit is refused by EVERY rank, after the
+        # collective (rank 1 alone holds it: raising there first would leave rank 0 waiting in the all-reduce)
+        assert allreduce_gram(mine_only.clone(), 5000 if rank == 0 else 70001) == 75001
+        try:
+            allreduce_gram(mine_only.clone(), 7 if rank == 0 else 1 << 24)
+            raise AssertionError("a sample count of 2^24 must be refused")
+        except ValueError as e:
+            assert "1 rank(s)" in str(e)
+
+        def refuse(*a, **kw):
+            raise AssertionError("gather_state_dict issued an object collective")
+
+        dist.all_gather_object = dist.gather_object = dist.broadcast_object_list = refuse
         merged = gather_state_dict(local, dst=0)
         if rank == 0:
             ok = len(merged) == 10
@@ -171,14 +184,18 @@ def _row_split_worker(rank, world, port, q, variant):
             ok &= (r.weight_g_idx is None) if actorder != "group" else torch.equal(r.weight_g_idx, perm)
             ok &= torch.equal(r.dequantized(wdt), w * 2)
             ok &= r.weight_shape.tolist() == [w.shape[0], K]
-        # a result that does not look like the layout every rank assumed is refused, not mis-sliced
-        if rank == 0:
-            qa_bad = types.SimpleNamespace(actorder=actorder, num_bits=bits, symmetric=symmetric, kernel_group_size=4)
-            try:
-                sh.gptq_quantize_row_split(Ws[1:2], None, qa_bad)
-                ok = False
-            except RuntimeError as e:
-                ok &= "layout every rank assumes" in str(e)
+        # a result that does not look like the layout every rank assumed is refused, not mis-sliced -- and refused by
+        # EVERY rank after the collective: only rank 0 sweeps the single row of this weight and can see the mismatch;
+        # raising there before the all-gather would leave rank 1 waiting in it.  The flag travels in
+        # the gathered buffer instead.
+        qa_bad = types.SimpleNamespace(actorder=actorder, num_bits=bits, symmetric=symmetric, kernel_group_size=4)
+        try:
+            sh.gptq_quantize_row_split(Ws[1:2], None, qa_bad)
+            ok = False
+        except RuntimeError as e:
+            ok &= "rank(s) [0]" in str(e) and "layout" in str(e)
+            ok &= ("layout every rank assumes" in str(e)) == (rank == 0)      # the detail only where it was seen
+        ok &= calls == {"all_gather": 2, "other": 0}
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
