@@ -118,6 +118,12 @@ def smooth_group(lins, weights, X, norm_vec, alpha=0.5):
     return dict(zip((n for n, _ in lins), new_w)), ops.scale_columns(X, s, divide=True)
 
 
+# QT_BENCH_SKIP=gram|chain: DIAGNOSTIC runs that leave one half of the step out (how long do the chains take with no Gram
+# pass beside them, and the reverse); the printed line is labelled "diagnostic" and is not a measurement of the metric.
+SKIP = os.environ.get("QT_BENCH_SKIP", "")
+_DIAG_G = {}
+
+
 def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0, per_sample=False, smooth=None):
     """One step: the hot path over one decoder layer.  Returns the packed outputs.
 
@@ -171,13 +177,20 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
                 wts, X = smooth_group(lins, weights, X, smooth[gname])
             # on the Gram stream a fresh accumulator (read later on the group's stream: record_stream below)
             acc = HessianAccumulator(K, dev) if sx is not None else _accumulator(K, dev, lane, slot_of[gname])
-            accumulate(acc, X, n_samples, per_sample)
+            if SKIP == "gram" and gname in _DIAG_G:      # diagnostic: the chains alone, on a Gram sum formed once
+                acc.G, acc.n = _DIAG_G[gname], n_samples
+            else:
+                accumulate(acc, X, n_samples, per_sample)
+                if SKIP == "gram":
+                    _DIAG_G[gname] = acc.G
         if sx is not None:
             ev = torch.cuda.Event()
             ev.record(sx)
             st.wait_event(ev)
             for t in [acc.G] + ([wts[n] for n, _ in lins] if wts is not weights else []):
                 t.record_stream(st)      # allocated on the Gram stream, read on this one
+        if SKIP == "chain":                              # diagnostic: the Gram passes alone
+            continue
         with torch.cuda.stream(st):
             res = gptq_quantize_shared([wts[n] for n, _ in lins], acc, qargs)
             for (lname, _), r in zip(lins, res):
@@ -660,6 +673,8 @@ def main():
             workload = (f"Llama-3-8B-shaped random-init GPTQ int4 g128 (W4A16, actorder={args.actorder}, "
                         "dampening 0.01, block 128), 512 synthetic calib samples x 384 tokens, "
                         f"1 decoder layer (7 Linears, {wpl} weights) per step per GPU")
+        if SKIP:
+            metric = f"DIAGNOSTIC (QT_BENCH_SKIP={SKIP}: half of the step left out) -- not a measurement of: " + metric
         line = {
             "metric": metric,
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

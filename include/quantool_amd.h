@@ -106,6 +106,18 @@ size_t qt_cholesky_inverse_upper_workspace_bytes(int K);
 int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
                               size_t workspace_bytes, qt_stream_t stream);
 
+/* The same factorisation for n_problems (1..16) Hessians of ONE size K in every launch of the chain: the Linear groups
+ * of a decoder layer that read different inputs of equal width (Llama: q/k/v, o, gate/up at K = hidden; Mixtral: the
+ * eight experts' w2 at K = intermediate) -- upstream factorises them one after another inside one `oneshot` call
+ * (base.py:161 -> quantize_weight per Linear).  Problem b: A + b * strideA (destroyed), U + b * strideU (elements;
+ * multiples of 4, >= K*K), info[b].  Each problem's factor is bit-identical to a single-problem call (same kernels,
+ * tile shapes, split-K decisions and summation orders per problem); the latency-bound panel kernels -- one workgroup
+ * per problem -- and the short products serve all problems per launch.  Workspace: n_problems times a single
+ * problem's share plus one copy of the item tables. */
+size_t qt_cholesky_inverse_upper_batched_workspace_bytes(int K, int n_problems);
+int qt_cholesky_inverse_upper_batched(float* A, int64_t strideA, int K, float* U, int64_t strideU, int32_t* info,
+                                      int n_problems, void* workspace, size_t workspace_bytes, qt_stream_t stream);
+
 /* ---- a10  minmax observer -> calculate_qparams ----------------------------------------------
  * W[R,K] (fp32, bf16 or fp16 by w_dtype -- every w_dtype / out_dtype argument below takes the three) -> scale, zp [R, K/group_size] fp32.  group_size <= 0:
  * channel-wise.  symmetric: scale = absmax/((qmax-qmin)/2), zp = 0.  scale_t / zp_t (may be

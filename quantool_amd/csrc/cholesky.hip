@@ -199,8 +199,15 @@ __device__ __forceinline__ void mma32_tn(const float* A, int lda, const float* B
 constexpr int POTF2_THREADS = 512, POTF2_WAVES = POTF2_THREADS / 64;   // 8 waves: the six trailing tiles of a step in one round
 __global__ __launch_bounds__(POTF2_THREADS) void potf2_kernel(const float* P, int64_t ldp, int n,
                                                     float* Rout, int64_t ldr,
-                                                    float* __restrict__ Rd, int32_t* info, int col0, int prio) {
+                                                    float* __restrict__ Rd, int32_t* info, int col0, int prio,
+                                                    int64_t bsP, int64_t bsRd) {
     qt_set_chain_prio(prio);
+    if (blockIdx.x) {      // problem b of a batch: one workgroup each
+        P += (size_t)blockIdx.x * bsP;
+        Rout += (size_t)blockIdx.x * bsP;
+        Rd += (size_t)blockIdx.x * bsRd;
+        info += blockIdx.x;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* As = sm;                // [NB][LDA]
     float* Xs = sm + NB * LDA;     // [4][32][32]  Xs[b][k][i] = X_b[k][i]
@@ -368,8 +375,14 @@ __global__ __launch_bounds__(POTF2_THREADS) void potf2_kernel(const float* P, in
 // B and Z may be the same panel (in place: a thread reads its columns before it writes them).
 __global__ __launch_bounds__(256) void trsm_rt_kernel(const float* __restrict__ Rd, int n,
                                                       const float* B, int64_t ldb,
-                                                      float* Z, int64_t ldz, int ncols, int prio) {
+                                                      float* Z, int64_t ldz, int ncols, int prio, int64_t bsRd,
+                                                      int64_t bsB) {
     qt_set_chain_prio(prio);
+    if (blockIdx.y) {      // problem b of a batch
+        Rd += (size_t)blockIdx.y * bsRd;
+        B += (size_t)blockIdx.y * bsB;
+        Z += (size_t)blockIdx.y * bsB;
+    }
     extern __shared__ __attribute__((aligned(16))) float Rs[];  // [RD_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < RD_STRIDE / 4; e += 256) ((f32x4*)Rs)[e] = ((const f32x4*)Rd)[e];
@@ -431,7 +444,12 @@ __global__ __launch_bounds__(256) void trsm_rt_kernel(const float* __restrict__ 
 //   Ydiag(b) : (R^-1)^T dense n x n at Y + (b*128)*(ldy+1) (zeros above the diagonal)
 __global__ __launch_bounds__(128) void trinv_batched_kernel(const float* __restrict__ Rd_all, int K,
                                                             float* __restrict__ Dinv_all,
-                                                            float* __restrict__ Y, int64_t ldy) {
+                                                            float* __restrict__ Y, int64_t ldy, int64_t bsW, int64_t bsY) {
+    if (blockIdx.y) {      // problem b of a batch
+        Rd_all += (size_t)blockIdx.y * bsW;
+        Dinv_all += (size_t)blockIdx.y * bsW;
+        Y += (size_t)blockIdx.y * bsY;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Rt = sm;             // [NB][LDT]  Rt[p][i] = R[i][p]
     float* Xs = sm + NB * LDT;  // [NB][LDP]
@@ -497,7 +515,12 @@ __global__ __launch_bounds__(128) void trinv_batched_kernel(const float* __restr
 // XT[k][m] = Y_II[m][k] for a w x w diagonal block of the lower-triangular Y (entries above the diagonal
 // of Y are not initialised outside the 128-blocks on the diagonal: written as zeros here)
 __global__ __launch_bounds__(256) void transpose_lower_block_kernel(const float* __restrict__ Y, int64_t ldy, int w,
-                                                                    float* __restrict__ XT, int ldx) {
+                                                                    float* __restrict__ XT, int ldx, int64_t bsY,
+                                                                    int64_t bsXT) {
+    if (blockIdx.z) {
+        Y += (size_t)blockIdx.z * bsY;
+        XT += (size_t)blockIdx.z * bsXT;
+    }
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // XT rows k = by.., cols m = bx..
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -514,7 +537,8 @@ __global__ __launch_bounds__(256) void transpose_lower_block_kernel(const float*
 
 // In-place flat reversal of the lower-triangular Y into the upper-triangular U:
 // U[i][j] = Y[K-1-i][K-1-j] for j >= i, strict lower triangle of U = 0.
-__global__ __launch_bounds__(256) void flat_reverse_lower_to_upper_kernel(float* __restrict__ U, int K) {
+__global__ __launch_bounds__(256) void flat_reverse_lower_to_upper_kernel(float* __restrict__ U, int K, int64_t bsU) {
+    U += (size_t)blockIdx.z * bsU;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= K || j < i) return;
@@ -535,8 +559,9 @@ __global__ __launch_bounds__(256) void flat_reverse_lower_to_upper_kernel(float*
 // Upstream's LinAlgError fallback, applied on the device so the host need not synchronise:
 // if the factorisation hit a non-positive pivot, U = I (plain round-to-nearest).
 __global__ __launch_bounds__(256) void identity_if_failed_kernel(float* __restrict__ U, int K,
-                                                                 const int32_t* __restrict__ info) {
-    if (*info == 0) return;
+                                                                 const int32_t* __restrict__ info, int64_t bsU) {
+    if (info[blockIdx.z] == 0) return;
+    U += (size_t)blockIdx.z * bsU;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j < K) U[(size_t)i * K + j] = (i == j) ? 1.0f : 0.0f;
@@ -544,38 +569,55 @@ __global__ __launch_bounds__(256) void identity_if_failed_kernel(float* __restri
 
 }  // namespace
 
-extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
-    if (K <= 0) return 0;
+// bytes of ONE problem's share of the workspace (a multiple of 256), without the bf16x3 item tables (shared by a batch)
+static size_t chol_problem_ws_bytes(int K, const CholG3Plan* g3) {
     const size_t nb = (K + NB - 1) / NB;
     // T panel [128, K] + T_I panel [512, K] + X_II [512, 512] + Rd, Dinv [nb][128*128] each + split-K slabs
     // (a split product writes splits * M * N floats with splits <= 2048 workgroups / tiles: <= 2048 * 128 * 128)
     const size_t split = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
-    int nbo_, nbi_;
-    return (size_t)NB * K * 4 + (size_t)NBO_MAX * K * 4 + (size_t)NBO_MAX * NBO_MAX * 4 +
-           nb * (NB * NB + RD_STRIDE) * 4 + split + 256 + chol_g3_ws_bytes(chol_blocks(K, nbo_, nbi_), K);
+    size_t n = (size_t)NB * K * 4 + (size_t)NBO_MAX * K * 4 + (size_t)NBO_MAX * NBO_MAX * 4 + nb * (NB * NB + RD_STRIDE) * 4 + split + 256;
+    if (g3->any) n += 2 * qt_align_up((size_t)3 * K * K * 2, 256) + (size_t)g3->max_slabs * 256 * 256 * 4 + 256;
+    return qt_align_up(n, 256);
 }
 
-extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
-                                         size_t workspace_bytes, qt_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    QT_CHECK_ARG(K > 0 && A && U && info, "qt_cholesky_inverse_upper: bad arguments");
-    const size_t need = qt_cholesky_inverse_upper_workspace_bytes(K);
+extern "C" size_t qt_cholesky_inverse_upper_batched_workspace_bytes(int K, int n_problems) {
+    if (K <= 0 || n_problems <= 0) return 0;
+    int nbo_, nbi_;
+    const CholG3Plan* g3 = chol_blocks(K, nbo_, nbi_);
+    return (size_t)n_problems * chol_problem_ws_bytes(K, g3) + g3->blob_bytes + 512;
+}
+
+extern "C" size_t qt_cholesky_inverse_upper_workspace_bytes(int K) {
+    return qt_cholesky_inverse_upper_batched_workspace_bytes(K, 1);
+}
+
+// n problems of one size K in every launch of the chain: problem b's matrices at A + b * strideA, U + b * strideU
+// (elements), its pivot flag at info[b].  Per problem the kernels, their launch shapes and the order of every sum are
+// those of a single-problem call (tile sizes and split-K decisions come from one problem's shape), so the factors are
+// bit-identical to n separate calls; what changes is that the latency-bound panel kernels (potf2: ONE workgroup per
+// problem; trsm, the short folds) and the block-row products serve all n problems per launch.
+static int chol_run(float* A, int64_t strideA, int K, float* U, int64_t strideU, int32_t* info, int nprob, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
+    const size_t need = qt_cholesky_inverse_upper_batched_workspace_bytes(K, nprob);
     if (!workspace || workspace_bytes < need) {
         qt_set_error("qt_cholesky_inverse_upper: workspace %zu < required %zu", workspace_bytes, need);
         return QT_ERR_WORKSPACE;
     }
     const int nblk = (K + NB - 1) / NB;
     char* ws = (char*)qt_align_up((size_t)workspace, 256);
-    float* T = (float*)ws;
-    float* TI = T + (size_t)NB * K;
     int NBO, NBI;
     const CholG3Plan* g3 = chol_blocks(K, NBO, NBI);
+    const size_t prob_bytes = chol_problem_ws_bytes(K, g3);
+    const int64_t sW = (int64_t)(prob_bytes / 4);            // one problem's workspace, in floats
+    const int64_t sA = nprob > 1 ? strideA : 0, sU = nprob > 1 ? strideU : 0;
+    float* T = (float*)ws;
+    float* TI = T + (size_t)NB * K;
     float* XT = TI + (size_t)NBO_MAX * K;
     float* Rd = XT + (size_t)NBO_MAX * NBO_MAX;
     float* Dinv = Rd + (size_t)nblk * RD_STRIDE;
     float* split_ws = Dinv + (size_t)nblk * NB * NB;
     const size_t split_ws_bytes = (size_t)2048 * NB * NB * 4 + (size_t)NBO_MAX * K * 4;
-    // bf16x3 products: plane copies of R and Y, slabs, item tables (only when some step uses them)
+    // bf16x3 products: plane copies of R and Y, slabs (per problem), item tables (one copy for the batch)
     unsigned short *Rpl = nullptr, *Ypl = nullptr;
     float* g3_slabs = nullptr;
     char* g3_tab = nullptr;
@@ -587,12 +629,12 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         Ypl = (unsigned short*)q;
         q += qt_align_up((size_t)3 * K * K * 2, 256);
         g3_slabs = (float*)q;
-        q += (size_t)g3->max_slabs * 256 * 256 * 4;
-        g3_tab = q;
+        g3_tab = (char*)qt_align_up((size_t)(ws + (size_t)nprob * prob_bytes), 256);
         QT_HIP(hipMemcpyAsync(g3_tab, g3->blob, g3->blob_bytes, hipMemcpyHostToDevice, stream));
     }
+    // where a block-row product's C lives decides its batch stride: A (factor phase) or the workspace (T_I)
     auto g3_row = [&](const G3Step& st, const unsigned short* Bplanes, int col_a0, int col_b0, int M, int N, float* C,
-                      int mode) -> int {
+                      int64_t bsC, int mode) -> int {
         G3Args a;
         a.Apl = Rpl;
         a.Bpl = Bplanes;
@@ -612,9 +654,23 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         a.n_items = st.n_items;
         a.red = (const G3Red*)(g3_tab + st.red_off);
         a.n_red = st.n_red;
+        a.batch = nprob;
+        a.bsApl = a.bsBpl = sW * 2;       // plane copies live in the problem's workspace (bf16 elements)
+        a.bsC = bsC;
+        a.bsSlabs = sW;
         return qt_gemm3_launch(a, stream);
     };
+    // an f32 product of the chain, for all problems: strides by where each operand lives
+    auto sgemm = [&](SgemmArgs& g, int64_t bsA_, int64_t bsB_, int64_t bsC_) -> int {
+        g.batch = nprob;
+        g.bsA = bsA_;
+        g.bsB = bsB_;
+        g.bsCin = g.bsCout = bsC_;
+        g.bs_split = sW;
+        return qt_sgemm_tn(g, stream);
+    };
     float* Y = U;
+    const int64_t sY = sU;
     const size_t inv_lds = (size_t)(NB * LDT + NB * LDP) * sizeof(float);
     const size_t potf2_lds = (size_t)(NB * LDA + 4 * 32 * 32) * sizeof(float);
     static QtOncePerDevice lds_attr;
@@ -629,7 +685,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
                                     (int)inv_lds);
         return e;
     }));
-    QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), stream));
+    QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * nprob, stream));
     const int prio = qt_chain_prio();
 
     // ---- A = R^T R over NBO-wide outer blocks, left-looking inside one; in place.  Outer level: right-looking
@@ -642,7 +698,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             const G3Step& st = g3->fac[Jb];
             float* C = A + (size_t)J0 * K + J0;
             if (st.n_items > 0) {
-                int rc = g3_row(st, Rpl, J0, J0, J1 - J0, K - J0, C, G3_SUB);
+                int rc = g3_row(st, Rpl, J0, J0, J1 - J0, K - J0, C, sA, G3_SUB);
                 if (rc) return rc;
             } else {
                 SgemmArgs g;
@@ -652,7 +708,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
                 g.Cout = C; g.ldcout = K;
                 g.M = J1 - J0; g.N = K - J0; g.kdim = J0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
                 g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
-                int rc = qt_sgemm_tn(g, stream);
+                int rc = sgemm(g, sA, sA, sA);
                 if (rc) return rc;
             }
         }
@@ -667,17 +723,17 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
                 g.Cin = Ajj; g.ldcin = K;
                 g.Cout = Ajj; g.ldcout = K;
                 g.M = nbj; g.N = K - j0; g.kdim = j0 - J0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
-                int rc = qt_sgemm_tn(g, stream);
+                int rc = sgemm(g, sA, sA, sA);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(POTF2_THREADS), potf2_lds, stream, (const float*)Ajj, (int64_t)K, nbj,
-                               Ajj, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0, prio);
+            hipLaunchKernelGGL(potf2_kernel, dim3(nprob), dim3(POTF2_THREADS), potf2_lds, stream, (const float*)Ajj, (int64_t)K, nbj,
+                               Ajj, (int64_t)K, Rd + (size_t)j * RD_STRIDE, info, j0, prio, sA, sW);
             QT_LAUNCH_CHECK();
             const int rest = K - j0 - nbj;
             if (rest > 0) {
-                hipLaunchKernelGGL(trsm_rt_kernel, dim3((rest + 127) / 128), dim3(256), RD_STRIDE * sizeof(float),
+                hipLaunchKernelGGL(trsm_rt_kernel, dim3((rest + 127) / 128, nprob), dim3(256), RD_STRIDE * sizeof(float),
                                    stream, (const float*)(Rd + (size_t)j * RD_STRIDE), nbj, (const float*)(Ajj + nbj),
-                                   (int64_t)K, Ajj + nbj, (int64_t)K, rest, prio);
+                                   (int64_t)K, Ajj + nbj, (int64_t)K, rest, prio, sW, sA);
                 QT_LAUNCH_CHECK();
             }
         }
@@ -687,7 +743,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             // the diagonal are ever read back)
             if (rem > 0) {
                 int rc = qt_split3_launch(A + (size_t)J0 * K + J0, K, J1 - J0, K - J0, Rpl + (size_t)J0 * K + J0, K,
-                                          plane_stride, 0, 0, 0, stream);
+                                          plane_stride, 0, 0, 0, stream, nprob, sA, sW * 2);
                 if (rc) return rc;
             }
         } else if (rem > 0) {
@@ -699,13 +755,13 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             g.Cout = A + (size_t)J1 * K + J1; g.ldcout = K;
             g.M = rem; g.N = rem; g.kdim = J1 - J0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
             g.upper_only = 1;
-            int rc = qt_sgemm_tn(g, stream);
+            int rc = sgemm(g, sA, sA, sA);
             if (rc) return rc;
         }
     }
     // ---- all diagonal-block inverses at once ----
-    hipLaunchKernelGGL(trinv_batched_kernel, dim3(nblk), dim3(NB), inv_lds, stream, (const float*)Rd, K, Dinv, Y,
-                       (int64_t)K);
+    hipLaunchKernelGGL(trinv_batched_kernel, dim3(nblk, nprob), dim3(NB), inv_lds, stream, (const float*)Rd, K, Dinv, Y,
+                       (int64_t)K, sW, sY);
     QT_LAUNCH_CHECK();
     // ---- Y = R^-T by NBI-row block rows ----
     for (int I0 = 0, Ib = 0; I0 < K; I0 += NBI, ++Ib) {
@@ -720,7 +776,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             g.Cin = nullptr; g.ldcin = 0;
             g.Cout = T; g.ldcout = K;
             g.M = nbi; g.N = i0 - I0; g.kdim = i0 - I0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
-            int rc = qt_sgemm_tn(g, stream);
+            int rc = sgemm(g, sA, sY, sW);
             if (rc) return rc;
             SgemmArgs t;
             t.A = Dinv + (size_t)i * NB * NB; t.lda = NB;
@@ -728,13 +784,14 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             t.Cin = nullptr; t.ldcin = 0;
             t.Cout = Y + (size_t)i0 * K + I0; t.ldcout = K;
             t.M = nbi; t.N = i0 - I0; t.kdim = nbi; t.k_mode = SG_K_FULL; t.mode = SG_MODE_NEG;
-            rc = qt_sgemm_tn(t, stream);
+            rc = sgemm(t, sW, sW, sY);
             if (rc) return rc;
         }
         // plane copy of the finished block row of Y (zeros above the diagonal), for the later rows' products
         auto split_row = [&]() -> int {
             if (!g3->any || I1 >= K) return QT_OK;
-            return qt_split3_launch(Y + (size_t)I0 * K, K, Wi, I1, Ypl + (size_t)I0 * K, K, plane_stride, 1, I0, 0, stream);
+            return qt_split3_launch(Y + (size_t)I0 * K, K, Wi, I1, Ypl + (size_t)I0 * K, K, plane_stride, 1, I0, 0, stream,
+                                    nprob, sY, sW * 2);
         };
         if (I0 == 0) {
             int rc0 = split_row();
@@ -744,7 +801,7 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         // left of the diagonal block: the K^3/3 of the inverse, one product per block row
         int rc;
         if (g3->any && g3->inv[Ib].n_items > 0) {
-            rc = g3_row(g3->inv[Ib], Ypl, I0, 0, Wi, I0, TI, G3_SET);
+            rc = g3_row(g3->inv[Ib], Ypl, I0, 0, Wi, I0, TI, sW, G3_SET);
         } else {
             SgemmArgs g;
             g.A = A + I0; g.lda = K;
@@ -753,11 +810,11 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
             g.Cout = TI; g.ldcout = K;
             g.M = Wi; g.N = I0; g.kdim = I0; g.k_mode = SG_K_FROM_N0; g.mode = SG_MODE_SET;
             g.split_ws = split_ws; g.split_ws_bytes = split_ws_bytes;
-            rc = qt_sgemm_tn(g, stream);
+            rc = sgemm(g, sA, sY, sW);
         }
         if (rc) return rc;
-        hipLaunchKernelGGL(transpose_lower_block_kernel, dim3((Wi + 31) / 32, (Wi + 31) / 32), dim3(256), 0, stream,
-                           (const float*)(Y + (size_t)I0 * K + I0), (int64_t)K, Wi, XT, NBO_MAX);
+        hipLaunchKernelGGL(transpose_lower_block_kernel, dim3((Wi + 31) / 32, (Wi + 31) / 32, nprob), dim3(256), 0, stream,
+                           (const float*)(Y + (size_t)I0 * K + I0), (int64_t)K, Wi, XT, NBO_MAX, sY, sW);
         QT_LAUNCH_CHECK();
         SgemmArgs t;
         t.A = XT; t.lda = NBO_MAX;
@@ -765,15 +822,31 @@ extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* inf
         t.Cin = nullptr; t.ldcin = 0;
         t.Cout = Y + (size_t)I0 * K; t.ldcout = K;
         t.M = Wi; t.N = I0; t.kdim = Wi; t.k_mode = SG_K_FULL; t.mode = SG_MODE_NEG;
-        rc = qt_sgemm_tn(t, stream);
+        rc = sgemm(t, sW, sW, sY);
         if (rc) return rc;
         rc = split_row();
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(flat_reverse_lower_to_upper_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, U, K);
+    hipLaunchKernelGGL(flat_reverse_lower_to_upper_kernel, dim3((K + 255) / 256, K, nprob), dim3(256), 0, stream, U, K, sU);
     QT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(identity_if_failed_kernel, dim3((K + 255) / 256, K), dim3(256), 0, stream, U, K,
-                       (const int32_t*)info);
+    hipLaunchKernelGGL(identity_if_failed_kernel, dim3((K + 255) / 256, K, nprob), dim3(256), 0, stream, U, K,
+                       (const int32_t*)info, sU);
     QT_LAUNCH_CHECK();
     return QT_OK;
+}
+
+extern "C" int qt_cholesky_inverse_upper(float* A, int K, float* U, int32_t* info, void* workspace,
+                                         size_t workspace_bytes, qt_stream_t stream_) {
+    QT_CHECK_ARG(K > 0 && A && U && info, "qt_cholesky_inverse_upper: bad arguments");
+    return chol_run(A, 0, K, U, 0, info, 1, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int qt_cholesky_inverse_upper_batched(float* A, int64_t strideA, int K, float* U, int64_t strideU, int32_t* info,
+                                                 int n_problems, void* workspace, size_t workspace_bytes,
+                                                 qt_stream_t stream_) {
+    QT_CHECK_ARG(K > 0 && A && U && info && n_problems >= 1 && n_problems <= SG_MAX_BATCH,
+                 "qt_cholesky_inverse_upper_batched: bad arguments (1 <= n_problems <= %d)", SG_MAX_BATCH);
+    QT_CHECK_ARG(n_problems == 1 || (strideA >= (int64_t)K * K && strideU >= (int64_t)K * K && strideA % 4 == 0 && strideU % 4 == 0),
+                 "qt_cholesky_inverse_upper_batched: strides must be multiples of 4 elements and >= K*K");
+    return chol_run(A, strideA, K, U, strideU, info, n_problems, workspace, workspace_bytes, (hipStream_t)stream_);
 }

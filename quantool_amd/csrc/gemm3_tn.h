@@ -53,6 +53,10 @@ struct G3Args {
     int n_items;
     const G3Red* red;            // device
     int n_red;
+    // batch > 1: `batch` problems of identical shape in one launch (one item / reduction table for all): problem b
+    // reads planes at Apl + b * bsApl, Bpl + b * bsBpl (elements), writes C + b * bsC and uses slabs + b * bsSlabs.
+    int batch = 1;
+    int64_t bsApl = 0, bsBpl = 0, bsC = 0, bsSlabs = 0;
 };
 
 // Enqueue the product (and the slab reduction when n_red > 0).  Returns qt_status.
@@ -61,8 +65,10 @@ int qt_gemm3_launch(const G3Args& a, hipStream_t stream);
 // fp32 [rows][ld_src] -> three bf16 planes at planes + q * plane_stride (pitch ld_pl).  cols % 4 == 0.
 // mask_upper != 0: elements with (col_g0 + c) > (row_g0 + r) are written as zeros (a lower-triangular
 // source whose upper part is not initialised).
+// batch > 1: problem b reads src + b * bs_src and writes planes + b * bs_planes (elements).
 int qt_split3_launch(const float* src, int64_t ld_src, int rows, int cols, unsigned short* planes, int64_t ld_pl,
-                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0, hipStream_t stream);
+                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0, hipStream_t stream, int batch = 1,
+                     int64_t bs_src = 0, int64_t bs_planes = 0);
 
 // Host-side item table of a block-row product: Tm x Tn tiles over k chunks [lo, c_end) (chunks of
 // G3_CHUNK_ROWS rows), lo = 0, or with tri != 0 lo = first chunk of row 256 * tj (B is lower-triangular in

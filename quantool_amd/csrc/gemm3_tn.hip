@@ -44,6 +44,7 @@ struct G3Params {
     int64_t ldc;
     float* slabs;
     const G3Item* items;
+    int64_t bsA_bytes, bsB_bytes, bsC, bsSlabs;   // problem blockIdx.y of a batch
 };
 
 template <int MODE>
@@ -56,6 +57,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
     const int wave_m = wave >> 2, wave_n = wave & 3;
     const bool group_b = wave >= 4;
 
+    if (blockIdx.y) {       // problem b of a batch of identical shapes
+        p.Apl += (size_t)blockIdx.y * p.bsA_bytes;
+        p.Bpl += (size_t)blockIdx.y * p.bsB_bytes;
+        p.C += (size_t)blockIdx.y * p.bsC;
+        p.slabs += (size_t)blockIdx.y * p.bsSlabs;
+    }
     const G3Item* itp = p.items + blockIdx.x;
     const int it_tile = __builtin_amdgcn_readfirstlane(itp->tile);
     const int c_lo = __builtin_amdgcn_readfirstlane(itp->c_lo);
@@ -227,7 +234,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm3_kernel(G3Params p) {
 // C[tile] (-)= sum of the tile's slabs in table order (one float4 per thread per step)
 __global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restrict__ slabs,
                                                            const G3Red* __restrict__ red, float* C, int64_t ldc,
-                                                           int M, int N, int mode) {
+                                                           int M, int N, int mode, int64_t bsSlabs, int64_t bsC) {
+    if (blockIdx.z) {
+        slabs += (size_t)blockIdx.z * bsSlabs;
+        C += (size_t)blockIdx.z * bsC;
+    }
     const G3Red t = red[blockIdx.x];
     const int ti = t.tile >> 16, tj = t.tile & 0xFFFF;
     const int part = blockIdx.y;   // 16 parts of 16 rows
@@ -268,7 +279,12 @@ __device__ __forceinline__ unsigned short bf16_bits_rne(float v) {
 
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int64_t ld_src, int cols,
                                                      unsigned short* __restrict__ planes, int64_t ld_pl,
-                                                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0) {
+                                                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0,
+                                                     int64_t bs_src, int64_t bs_planes) {
+    if (blockIdx.z) {
+        src += (size_t)blockIdx.z * bs_src;
+        planes += (size_t)blockIdx.z * bs_planes;
+    }
     const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int r = blockIdx.y;
     if (c4 >= cols) return;
@@ -324,26 +340,35 @@ int qt_gemm3_launch(const G3Args& a, hipStream_t stream) {
     p.ldc = a.ldc;
     p.slabs = a.slabs;
     p.items = a.items;
-    if (a.mode == G3_SUB) hipLaunchKernelGGL((gemm3_kernel<G3_SUB>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
-    else if (a.mode == G3_ADD) hipLaunchKernelGGL((gemm3_kernel<G3_ADD>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
-    else hipLaunchKernelGGL((gemm3_kernel<G3_SET>), dim3(a.n_items), dim3(NTHREADS), 0, stream, p);
+    const int nb = a.batch > 1 ? a.batch : 1;
+    QT_CHECK_ARG(nb <= 65535 && (a.bsApl % 8) == 0 && (a.bsBpl % 8) == 0, "qt_gemm3_launch: batch %d / plane strides unsupported", nb);
+    p.bsA_bytes = a.bsApl * 2;
+    p.bsB_bytes = a.bsBpl * 2;
+    p.bsC = a.bsC;
+    p.bsSlabs = a.bsSlabs;
+    const dim3 grid(a.n_items, nb);
+    if (a.mode == G3_SUB) hipLaunchKernelGGL((gemm3_kernel<G3_SUB>), grid, dim3(NTHREADS), 0, stream, p);
+    else if (a.mode == G3_ADD) hipLaunchKernelGGL((gemm3_kernel<G3_ADD>), grid, dim3(NTHREADS), 0, stream, p);
+    else hipLaunchKernelGGL((gemm3_kernel<G3_SET>), grid, dim3(NTHREADS), 0, stream, p);
     QT_LAUNCH_CHECK();
     if (a.n_red > 0) {
-        hipLaunchKernelGGL(gemm3_reduce_kernel, dim3(a.n_red, 16), dim3(256), 0, stream, (const float*)a.slabs, a.red,
-                           a.C, a.ldc, a.M, a.N, a.mode);
+        hipLaunchKernelGGL(gemm3_reduce_kernel, dim3(a.n_red, 16, nb), dim3(256), 0, stream, (const float*)a.slabs, a.red,
+                           a.C, a.ldc, a.M, a.N, a.mode, a.bsSlabs, a.bsC);
         QT_LAUNCH_CHECK();
     }
     return QT_OK;
 }
 
 int qt_split3_launch(const float* src, int64_t ld_src, int rows, int cols, unsigned short* planes, int64_t ld_pl,
-                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0, hipStream_t stream) {
+                     int64_t plane_stride, int mask_upper, int row_g0, int col_g0, hipStream_t stream, int batch,
+                     int64_t bs_src, int64_t bs_planes) {
     if (rows <= 0 || cols <= 0) return QT_OK;
     QT_CHECK_ARG(cols % 4 == 0 && ld_src % 4 == 0 && ld_pl % 4 == 0 && plane_stride % 4 == 0 &&
                      ((uintptr_t)src & 15) == 0 && ((uintptr_t)planes & 7) == 0,
                  "qt_split3_launch: columns / pitches must be multiples of 4 and the pointers aligned");
-    hipLaunchKernelGGL(split3_kernel, dim3((cols / 4 + 255) / 256, rows), dim3(256), 0, stream, src, ld_src, cols, planes,
-                       ld_pl, plane_stride, mask_upper, row_g0, col_g0);
+    QT_CHECK_ARG(bs_src % 4 == 0 && bs_planes % 4 == 0, "qt_split3_launch: batch strides must be multiples of 4");
+    hipLaunchKernelGGL(split3_kernel, dim3((cols / 4 + 255) / 256, rows, batch > 1 ? batch : 1), dim3(256), 0, stream, src,
+                       ld_src, cols, planes, ld_pl, plane_stride, mask_upper, row_g0, col_g0, bs_src, bs_planes);
     QT_LAUNCH_CHECK();
     return QT_OK;
 }

@@ -10,6 +10,8 @@
 
 enum { SG_MODE_SUB = 0, SG_MODE_SET = 1, SG_MODE_NEG = 2 };
 enum { SG_K_FULL = 0, SG_K_FROM_N0 = 1 };  // SG_K_FROM_N0: B[k][n] == 0 for k < n (skip them)
+constexpr int SG_MAX_GROUPS = 16;          // row groups of one stacked product / problems of one batched sweep
+constexpr int SG_MAX_BATCH = 16;           // problems of one batched factorisation
 
 struct SgemmArgs {
     const float* A; int64_t lda;
@@ -33,8 +35,23 @@ struct SgemmArgs {
     // A[J1:, J1:] -= R^T R): tiles entirely below the diagonal are skipped.  Cin == Cout (in place) is
     // allowed in every mode: a thread reads its C elements before it writes them and no other does.
     int upper_only = 0;
+    // ---- several problems in one launch (results per problem are bit-identical to separate launches:
+    // tile shape, split-K decision and k order are taken from ONE problem's shape, never from the batch) ----
+    // batch > 1: `batch` independent problems of identical shape; problem b reads / writes operand + b * stride
+    // (elements).  The Cholesky chains of a layer's equal-K Hessians (qt_cholesky_inverse_upper_batched).
+    int batch = 1;
+    int64_t bsA = 0, bsB = 0, bsCin = 0, bsCout = 0;
+    int64_t bs_split = 0;          // split-K slabs of problem b at split_ws + b * bs_split (>= splits * M * N)
+    // n_groups > 0: ONE product over stacked rows whose B operand depends on the row range: rows
+    // [group_m_end[g-1], group_m_end[g]) of the output (columns of A) multiply B + g * group_bsB.  Boundaries are
+    // multiples of 128 (no tile straddles two groups).  The sweeps of Linears with different factors U, stacked
+    // (qt_gptq_sweep_grouped).
+    int n_groups = 0;
+    int64_t group_bsB = 0;
+    int group_m_end[SG_MAX_GROUPS] = {};
     // internal (set by qt_sgemm_tn)
     int k_chunk = 0;
+    int n_splits = 1;
     int fast_interior = 1;
 };
 
@@ -43,4 +60,5 @@ int qt_sgemm_tn(const SgemmArgs& a, hipStream_t stream);
 
 // Ordered slab reduction (shared by the split-K paths): Cout = mode(Cin, sum_z slabs[z]).
 int qt_splitk_reduce(const float* slabs, int splits, int M, int N, const float* Cin, int64_t ldcin, float* Cout,
-                     int64_t ldcout, int mode, hipStream_t stream);
+                     int64_t ldcout, int mode, hipStream_t stream, int batch = 1, int64_t bs_slabs = 0, int64_t bs_cin = 0,
+                     int64_t bs_cout = 0);

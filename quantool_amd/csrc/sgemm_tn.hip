@@ -32,16 +32,30 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
     const int wave_m = wave >> 1, wave_n = wave & 1;   // WGN == 2
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (p.upper_only && m0 >= n0 + BN) return;   // every row of this tile lies below every column: not wanted
+    int zsplit = blockIdx.z;
+    if (p.batch > 1) {        // problem b of a batch of identical shapes: every operand at its own stride
+        const int b = zsplit / p.n_splits;
+        zsplit -= b * p.n_splits;
+        p.A += (size_t)b * p.bsA;
+        p.B += (size_t)b * p.bsB;
+        if (p.Cin) p.Cin += (size_t)b * p.bsCin;
+        p.Cout += (size_t)b * p.bsCout;
+    }
+    if (p.n_groups > 0) {     // stacked rows: the B operand of this tile's row group (boundaries are multiples of BM)
+        int g = 0;
+        while (g + 1 < p.n_groups && m0 >= p.group_m_end[g]) ++g;
+        p.B += (size_t)g * p.group_bsB;
+    }
     const bool tile_inside = p.fast_interior && m0 + BM <= p.M && n0 + BN <= p.N;   // wave-uniform
 
     int k_begin = 0;
     if (p.k_mode == SG_K_FROM_N0) k_begin = n0 / BK * BK;
     int k_end = p.kdim;
     if (p.k_chunk > 0) {  // split-K: this z-slice owns [z*k_chunk, (z+1)*k_chunk)
-        const int lo = blockIdx.z * p.k_chunk, hi = lo + p.k_chunk;
+        const int lo = zsplit * p.k_chunk, hi = lo + p.k_chunk;
         k_begin = k_begin > lo ? k_begin : lo;
         k_end = k_end < hi ? k_end : hi;
-        p.Cout += (size_t)blockIdx.z * (size_t)p.M * (size_t)p.N;
+        p.Cout += (size_t)zsplit * (size_t)p.M * (size_t)p.N;
     }
 
     const bool a_vec = (p.lda % 4 == 0) && (((uintptr_t)p.A & 15) == 0);
@@ -232,8 +246,15 @@ struct RingArgs {
     const float* Cin; int64_t ldcin;
     float* Cout; int64_t ldcout;
     int M, N, kdim, chain_len;     // chain_len > 0
-    int tiles_n, n_tiles;          // n_tiles = tiles_m * tiles_n (upper_only: listed tiles only)
+    int tiles_n, n_tiles;          // n_tiles = tiles_m * tiles_n (upper_only: listed tiles only), per problem
     int upper_only;
+    // several problems in one launch (SgemmArgs): `batch` problems of this shape at operand strides, walked as
+    // batch * n_tiles tiles; or row groups whose B operand sits at B + g * group_bsB
+    int batch;
+    int64_t bsA, bsB, bsCin, bsCout;
+    int n_groups;
+    int64_t group_bsB;
+    int group_m_end[SG_MAX_GROUPS];
 };
 
 __device__ __forceinline__ void glds16_one(unsigned voff, const void* sbase, unsigned lds_dst) {
@@ -259,13 +280,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int h = lane >> 5, l31 = lane & 31;
     const int steps = p.kdim / RBK;                 // per tile
     const int fold_every = p.chain_len / RBK;
-    const int my_tiles = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int all_tiles = p.n_tiles * p.batch;
+    const int my_tiles = (all_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     if (my_tiles <= 0) return;
     const int total = my_tiles * steps;             // stages this workgroup streams
 
-    // tile it (0 .. my_tiles) of this workgroup -> (m0, n0)
-    auto tile_origin = [&](int it, int& m0, int& n0) {
-        const int t = (int)blockIdx.x + it * (int)gridDim.x;
+    // tile it (0 .. my_tiles) of this workgroup -> (m0, n0) and the element offsets of its problem's / row group's operands
+    auto tile_origin = [&](int it, int& m0, int& n0, size_t& offA, size_t& offB, size_t& offCin, size_t& offCout) {
+        int t = (int)blockIdx.x + it * (int)gridDim.x;
+        offA = offB = offCin = offCout = 0;
+        if (p.batch > 1) {
+            const int b = t / p.n_tiles;
+            t -= b * p.n_tiles;
+            offA = (size_t)b * p.bsA;
+            offB = (size_t)b * p.bsB;
+            offCin = (size_t)b * p.bsCin;
+            offCout = (size_t)b * p.bsCout;
+        }
         int tm, tn;
         if (p.upper_only) {
             // tiles with tn >= tm, listed row by row: row tm holds tiles_n - tm of them (tiles_m == tiles_n)
@@ -279,6 +310,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         m0 = tm * RBM;
         n0 = tn * RBN;
+        if (p.n_groups > 0) {
+            int g = 0;
+            while (g + 1 < p.n_groups && m0 >= p.group_m_end[g]) ++g;
+            offB = (size_t)g * p.group_bsB;
+        }
     };
 
     // DMA geometry: thread t moves 16 bytes of k row (t >> 5), columns 4 * (t & 31) .. + 3 of each panel; a wave's
@@ -293,9 +329,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float *is_a, *is_b;
     {
         int m0i, n0i;
-        tile_origin(0, m0i, n0i);
-        is_a = p.A + m0i;
-        is_b = p.B + n0i;
+        size_t oa, ob, oci, oco;
+        tile_origin(0, m0i, n0i, oa, ob, oci, oco);
+        is_a = p.A + oa + m0i;
+        is_b = p.B + ob + n0i;
     }
     const size_t a_step = (size_t)RBK * p.lda, b_step = (size_t)RBK * p.ldb;
     auto issue_next = [&]() {
@@ -308,9 +345,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             ++is_it;
             if (is_it < my_tiles) {
                 int m0i, n0i;
-                tile_origin(is_it, m0i, n0i);
-                is_a = p.A + m0i;
-                is_b = p.B + n0i;
+                size_t oa, ob, oci, oco;
+                tile_origin(is_it, m0i, n0i, oa, ob, oci, oco);
+                is_a = p.A + oa + m0i;
+                is_b = p.B + ob + n0i;
             }
         } else {
             is_a += a_step;
@@ -328,9 +366,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int cstep_in = (int)((size_t)p.ldcin * 4), cstep_out = (int)((size_t)p.ldcout * 4);
     // register r of a 32x32 accumulator is row (r & 3) + 8 (r >> 2) (+ 4 h): the per-lane offset walks the rows
     // (+1 row, and +5 rows after every fourth), the sub-tile j is an immediate
+    size_t c_off_in = 0, c_off_out = 0;      // the current tile's problem (batch): element offsets of its C
     auto load_c = [&](int m0, int n0) {
         const int rw = m0 + wave_m * 32, cw = n0 + wave_n * 64;      // wave-uniform
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cin + (size_t)rw * p.ldcin + cw), 0, 0x7FFFFFFF, 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cin + c_off_in + (size_t)rw * p.ldcin + cw), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int soff = ((r & 3) + 8 * (r >> 2)) * cstep_in;      // scalar; the sub-tile j is an immediate
@@ -341,7 +380,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     auto store_c = [&](int m0, int n0) {      // Cout = cpre - acc
         const int rw = m0 + wave_m * 32, cw = n0 + wave_n * 64;
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cout + (size_t)rw * p.ldcout + cw), 0, 0x7FFFFFFF, 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cout + c_off_out + (size_t)rw * p.ldcout + cw), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int soff = ((r & 3) + 8 * (r >> 2)) * cstep_out;
@@ -359,7 +398,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     // prologue: first tile's C (older than every DMA), stages 0 and 1
     int m0, n0;
-    tile_origin(0, m0, n0);
+    {
+        size_t oa, ob;
+        tile_origin(0, m0, n0, oa, ob, c_off_in, c_off_out);
+    }
     load_c(m0, n0);
     issue_next();
     issue_next();
@@ -421,17 +463,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         store_c(m0, n0);
         __builtin_amdgcn_sched_barrier(0);
         batch_prev = 32;
-        if (it + 1 < my_tiles) tile_origin(it + 1, m0, n0);
+        if (it + 1 < my_tiles) {
+            size_t oa, ob;
+            tile_origin(it + 1, m0, n0, oa, ob, c_off_in, c_off_out);     // after this tile's stores were issued
+        }
     }
 }
 
 // Cout = mode(Cin, sum_z slab[z]) in ascending z (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int M,
                                                             int N, const float* __restrict__ Cin, int64_t ldcin,
-                                                            float* __restrict__ Cout, int64_t ldcout, int mode) {
+                                                            float* __restrict__ Cout, int64_t ldcout, int mode,
+                                                            int64_t bs_slabs, int64_t bs_cin, int64_t bs_cout) {
     const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int row = blockIdx.y;
     if (col >= N) return;
+    if (blockIdx.z) {       // problem b of a batch
+        slabs += (size_t)blockIdx.z * bs_slabs;
+        if (Cin) Cin += (size_t)blockIdx.z * bs_cin;
+        Cout += (size_t)blockIdx.z * bs_cout;
+    }
     const size_t mn = (size_t)M * N;
     if (col + 3 < N && (N & 3) == 0) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -467,7 +518,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <int BM, int BN>
 int launch(const SgemmArgs& a, hipStream_t stream, int splits = 1) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits * (a.batch > 1 ? a.batch : 1));
     // 128x128 MODE_SUB tiles on 8 waves (four waves per SIMD) unless QT_SGEMM_SUB_WAVES=4
     static const bool sub8 = [] {
         const char* e = getenv("QT_SGEMM_SUB_WAVES");
@@ -503,15 +554,22 @@ int launch(const SgemmArgs& a, hipStream_t stream, int splits = 1) {
 }  // namespace
 
 int qt_splitk_reduce(const float* slabs, int splits, int M, int N, const float* Cin, int64_t ldcin, float* Cout,
-                     int64_t ldcout, int mode, hipStream_t stream) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N / 4 + 255) / 256 + 1, M), dim3(256), 0, stream, slabs, splits, M,
-                       N, Cin, ldcin, Cout, ldcout, mode);
+                     int64_t ldcout, int mode, hipStream_t stream, int batch, int64_t bs_slabs, int64_t bs_cin,
+                     int64_t bs_cout) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((N / 4 + 255) / 256 + 1, M, batch > 1 ? batch : 1), dim3(256), 0, stream,
+                       slabs, splits, M, N, Cin, ldcin, Cout, ldcout, mode, bs_slabs, bs_cin, bs_cout);
     QT_LAUNCH_CHECK();
     return QT_OK;
 }
 
 int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
     if (a_.M <= 0 || a_.N <= 0) return QT_OK;
+    QT_CHECK_ARG(a_.batch >= 1 && a_.batch <= SG_MAX_BATCH && a_.n_groups >= 0 && a_.n_groups <= SG_MAX_GROUPS &&
+                     !(a_.batch > 1 && a_.n_groups > 0),
+                 "qt_sgemm_tn: batch %d / row groups %d unsupported", a_.batch, a_.n_groups);
+    for (int g = 0; g < a_.n_groups; ++g)
+        QT_CHECK_ARG(a_.group_m_end[g] % 128 == 0 && (g == 0 || a_.group_m_end[g] >= a_.group_m_end[g - 1]),
+                     "qt_sgemm_tn: row group %d ends at %d (boundaries must be ascending multiples of 128)", g, a_.group_m_end[g]);
     static const int fast_interior = [] {
         const char* e = getenv("QT_SGEMM_INTERIOR");
         return (e && atoi(e) == 0) ? 0 : 1;
@@ -542,20 +600,22 @@ int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
         if (chunk < min_chunk) chunk = min_chunk;
         splits = (a.kdim + chunk - 1) / chunk;
         const size_t need = (size_t)splits * a.M * a.N * sizeof(float);
-        if (splits >= 2 && need <= a.split_ws_bytes) {
+        // (the decision depends on ONE problem's shape only: a batch takes the path -- hence the bits -- of its members)
+        if (splits >= 2 && need <= a.split_ws_bytes && (a.batch <= 1 || (size_t)a.bs_split * sizeof(float) >= need)) {
             SgemmArgs part = a;
             part.Cin = nullptr;
             part.ldcin = 0;
             part.Cout = a.split_ws;
             part.ldcout = a.N;
+            part.bsCin = 0;
+            part.bsCout = a.bs_split;
             part.mode = SG_MODE_SET;
             part.k_chunk = chunk;
+            part.n_splits = splits;
             const int rc = launch<128, 128>(part, stream, splits);
             if (rc) return rc;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((a.N / 4 + 255) / 256 + 1, a.M), dim3(256), 0, stream,
-                               (const float*)a.split_ws, splits, a.M, a.N, a.Cin, a.ldcin, a.Cout, a.ldcout, a.mode);
-            QT_LAUNCH_CHECK();
-            return QT_OK;
+            return qt_splitk_reduce(a.split_ws, splits, a.M, a.N, a.Cin, a.ldcin, a.Cout, a.ldcout, a.mode, stream, a.batch,
+                                    a.bs_split, a.bsCin, a.bsCout);
         }
     }
     // MODE_SUB products with enough 128x128 tiles: the LDS-DMA ring kernel, persistent over its tiles
@@ -579,8 +639,14 @@ int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
         r.tiles_n = tn;
         r.upper_only = a.upper_only;
         r.n_tiles = a.upper_only ? tn * (tn + 1) / 2 : tm * tn;
+        r.batch = a.batch > 1 ? a.batch : 1;
+        r.bsA = a.bsA; r.bsB = a.bsB; r.bsCin = a.bsCin; r.bsCout = a.bsCout;
+        r.n_groups = a.n_groups;
+        r.group_bsB = a.group_bsB;
+        for (int g = 0; g < SG_MAX_GROUPS; ++g) r.group_m_end[g] = a.group_m_end[g];
         if (r.n_tiles >= ring_min_tiles) {
-            const int grid = r.n_tiles >= 2 * 256 ? 2 * 256 : r.n_tiles;      // two workgroups per CU
+            const int all = r.n_tiles * r.batch;
+            const int grid = all >= 2 * 256 ? 2 * 256 : all;      // two workgroups per CU
             hipLaunchKernelGGL(sgemm_ring_kernel, dim3(grid), dim3(512), 0, stream, r);
             QT_LAUNCH_CHECK();
             return QT_OK;

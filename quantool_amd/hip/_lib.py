@@ -38,6 +38,9 @@ SIGNATURES = {
     "qt_argsort_desc": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "qt_cholesky_inverse_upper_workspace_bytes": (c_size_t, [c_int]),
     "qt_cholesky_inverse_upper": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "qt_cholesky_inverse_upper_batched_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "qt_cholesky_inverse_upper_batched": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                                  c_size_t, c_void_p]),
     "qt_group_minmax_qparams": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "qt_weight_gather_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,

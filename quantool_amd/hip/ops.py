@@ -269,6 +269,30 @@ def cholesky_inverse_upper(A: torch.Tensor, U_out: Optional[torch.Tensor] = None
     return U, info
 
 
+MAX_BATCH = 16      # problems per batched factorisation / groups per grouped sweep (SG_MAX_BATCH / SG_MAX_GROUPS)
+
+
+def cholesky_inverse_upper_batched(A: torch.Tensor, U: torch.Tensor):
+    """n problems of one size in every launch of the chain.  ``A``: [n, K, K] fp32 (flipped damped Hessians, destroyed)
+    -- or any tensor whose [b] slices are contiguous K x K matrices at a uniform stride -- ``U`` likewise (written).
+    Returns info int32[n] (device).  Bit-identical per problem to ``cholesky_inverse_upper``."""
+    lib = load()
+    _req(A, torch.float32, "A", 3)
+    _req(U, torch.float32, "U", 3)
+    n, K, K2 = A.shape
+    if K != K2 or tuple(U.shape) != (n, K, K) or not (1 <= n <= MAX_BATCH):
+        raise ValueError(f"A / U must be [n <= {MAX_BATCH}, K, K], got {tuple(A.shape)} / {tuple(U.shape)}")
+    for name, t in (("A", A), ("U", U)):
+        if t.stride(2) != 1 or t.stride(1) != K or (n > 1 and (t.stride(0) < K * K or t.stride(0) % 4)):
+            raise ValueError(f"{name}: every [b] slice must be a contiguous K x K matrix at a stride that is a multiple of 4")
+    info = torch.zeros(n, dtype=torch.int32, device=A.device)
+    ws = workspace(lib.qt_cholesky_inverse_upper_batched_workspace_bytes(K, n), A.device, "chol")
+    check("qt_cholesky_inverse_upper_batched", lib.qt_cholesky_inverse_upper_batched(
+        A.data_ptr(), A.stride(0) if n > 1 else K * K, K, U.data_ptr(), U.stride(0) if n > 1 else K * K, info.data_ptr(), n,
+        ws.data_ptr(), ws.numel(), _stream()))
+    return info
+
+
 # ---- a10 ----------------------------------------------------------------------------------
 def group_minmax_qparams(W: torch.Tensor, group_size: int, symmetric: bool = True, num_bits: int = 4):
     """Returns (scale[R,G], zp[R,G], scale_t[G,R], zp_t[G,R]) fp32."""
