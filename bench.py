@@ -121,6 +121,7 @@ def smooth_group(lins, weights, X, norm_vec, alpha=0.5):
 # QT_BENCH_SKIP=gram|chain: DIAGNOSTIC runs that leave one half of the step out (how long do the chains take with no Gram
 # pass beside them, and the reverse); the printed line is labelled "diagnostic" and is not a measurement of the metric.
 SKIP = os.environ.get("QT_BENCH_SKIP", "")
+BATCH_CHAINS = os.environ.get("QT_BATCH_CHAINS", "1") != "0"
 _DIAG_G = {}
 
 
@@ -132,7 +133,7 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
     The Gram passes share one further stream, smallest in_features first (below).  `lane` selects one
     of two stream sets so that two consecutive layers (independent units in this per-Linear mode,
     exactly as across GPUs) can be in flight at once."""
-    from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
+    from quantool_amd.engine.gptq_linear import HessianAccumulator, batchable, gptq_quantize_batched
 
     dev = next(iter(acts.values())).device
     outs = {}
@@ -156,6 +157,25 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
             _STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1 if xmode == "prio" else 0)
         sx = _STREAMS[key]
         sx.wait_stream(main)
+    pending = []
+
+    def run_chains(members):
+        """factorise + sweep + pack for one batch of groups (usually one group, or all groups of one in_features)"""
+        st = members[0][5]
+        for gname, K, lins, wts, acc, st_g, ev in members:
+            if ev is not None:
+                st.wait_event(ev)
+                for t in [acc.G] + ([wts[n] for n, _ in lins] if wts is not weights else []):
+                    t.record_stream(st)      # allocated on the Gram stream, read on this one
+            elif st_g is not st:
+                st.wait_stream(st_g)
+        with torch.cuda.stream(st):
+            res = gptq_quantize_batched([([wts[n] for n, _ in lins], acc) for _, _, lins, wts, acc, _, _ in members], qargs)
+            for (_, _, lins, _, _, _, _), rs in zip(members, res):
+                for (lname, _), r in zip(lins, rs):
+                    outs[f"{lname}.weight_packed"] = r.weight_packed
+                    outs[f"{lname}.weight_scale"] = r.weight_scale
+
     slot_of = {g[0]: gi % 4 for gi, g in enumerate(groups)}      # largest in_features -> slot 0, as in rounds 1-2
     order = groups if (sx is None or os.environ.get("QT_BENCH_XTX_ORDER") == "big") else sorted(groups, key=lambda g: g[1])
     for gname, K, lins in order:      # a group's chain is issued right behind its Gram pass (the host never runs ahead
@@ -183,20 +203,21 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
                 accumulate(acc, X, n_samples, per_sample)
                 if SKIP == "gram":
                     _DIAG_G[gname] = acc.G
+        ev = None
         if sx is not None:
             ev = torch.cuda.Event()
             ev.record(sx)
-            st.wait_event(ev)
-            for t in [acc.G] + ([wts[n] for n, _ in lins] if wts is not weights else []):
-                t.record_stream(st)      # allocated on the Gram stream, read on this one
         if SKIP == "chain":                              # diagnostic: the Gram passes alone
             continue
-        with torch.cuda.stream(st):
-            res = gptq_quantize_shared([wts[n] for n, _ in lins], acc, qargs)
-            for (lname, _), r in zip(lins, res):
-                outs[f"{lname}.weight_packed"] = r.weight_packed
-                outs[f"{lname}.weight_scale"] = r.weight_scale
-            del acc, res
+        pending.append((gname, K, lins, wts, acc, st, ev))
+        if not BATCH_CHAINS or sx is None:
+            run_chains([pending.pop()])
+    # Batched chains (default): the layer's groups of equal in_features go through ONE chain of launches -- one batched
+    # factorisation, one stacked sweep (gptq_quantize_batched) -- on the stream of the first of them, behind the Gram
+    # passes of all of them.  QT_BATCH_CHAINS=0: a chain per group on its own stream (rounds 1-3).
+    if pending:
+        for idx in batchable([([w[n] for n, _ in l], a) for _, _, l, w, a, _, _ in pending]):
+            run_chains([pending[i] for i in idx])
     return outs
 
 

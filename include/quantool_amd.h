@@ -146,6 +146,18 @@ int qt_gptq_sweep(float* W, int R, int K, const float* U, const float* scale_t, 
                   int G, const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt,
                   float* loss, void* workspace, size_t workspace_bytes, qt_stream_t stream);
 
+/* The sweeps of several Linear groups of ONE in_features K as one stacked sweep: W holds the rows of all groups
+ * (group g: rows [row_end[g-1], row_end[g]), row_end a HOST array, every boundary but the last a multiple of 128),
+ * group g's factor is U + g * strideU (elements) and its column groups g_idx + g * K; scale_t / zp_t / Qt / loss span the
+ * stacked rows.  Rows are independent given their factor, and per row the operation sequence is qt_gptq_sweep's, so
+ * every group's outputs are bit-identical to its own qt_gptq_sweep call; the block kernel and the update products run
+ * once per 128-column block for all groups (a Llama layer's q/k/v + o + gate/up: 38 912 rows instead of three launches
+ * of 6144 / 4096 / 28 672). */
+int qt_gptq_sweep_grouped(float* W, int R, int K, const float* U, int64_t strideU, int n_groups, const int32_t* row_end,
+                          const float* scale_t, const float* zp_t, int G, const int32_t* g_idx, int blocksize,
+                          int num_bits, int8_t* Qt, float* loss, void* workspace, size_t workspace_bytes,
+                          qt_stream_t stream);
+
 /* ---- a14  pack_to_int32 (save path, base.py:188) --------------------------------------------
  * packed[R, ceil(K/8)] int32: nibble j of word w = level(column 8w+j) + 8.  col_src (int32[K],
  * may be NULL) maps an output column to the sweep position holding it (undoes actorder). */

@@ -568,7 +568,7 @@ int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
                      !(a_.batch > 1 && a_.n_groups > 0),
                  "qt_sgemm_tn: batch %d / row groups %d unsupported", a_.batch, a_.n_groups);
     for (int g = 0; g < a_.n_groups; ++g)
-        QT_CHECK_ARG(a_.group_m_end[g] % 128 == 0 && (g == 0 || a_.group_m_end[g] >= a_.group_m_end[g - 1]),
+        QT_CHECK_ARG((a_.group_m_end[g] % 128 == 0 || g == a_.n_groups - 1) && (g == 0 || a_.group_m_end[g] >= a_.group_m_end[g - 1]),
                      "qt_sgemm_tn: row group %d ends at %d (boundaries must be ascending multiples of 128)", g, a_.group_m_end[g]);
     static const int fast_interior = [] {
         const char* e = getenv("QT_SGEMM_INTERIOR");

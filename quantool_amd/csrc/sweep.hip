@@ -31,6 +31,19 @@ constexpr int SB = 32;     // register sub-block
 constexpr int ROWS = 128;  // rows (lanes) per workgroup: 2 waves
 constexpr size_t SWEEP_LDS = (size_t)(BS * BS + BS * ROWS + 2 * BS) * sizeof(float);
 
+// Row groups of a stacked sweep (qt_gptq_sweep_grouped): rows [row_end[g-1], row_end[g]) belong to problem g, whose factor
+// is U + g * bsU and whose column groups are g_idx + g * K.  n == 0: one problem.
+struct SweepGroups {
+    int n;
+    int64_t bsU;
+    int row_end[SG_MAX_GROUPS];
+};
+__device__ __forceinline__ int sweep_group_of(const SweepGroups& sg, int row0) {
+    int g = 0;
+    while (g + 1 < sg.n && row0 >= sg.row_end[g]) ++g;
+    return g;
+}
+
 __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W, int R, int K,
                                                            const float* __restrict__ U,
                                                            const float* __restrict__ scale_t,
@@ -38,8 +51,13 @@ __global__ __launch_bounds__(ROWS) void sweep_block_kernel(float* __restrict__ W
                                                            const int32_t* __restrict__ g_idx, int i1, int cnt,
                                                            float qmin, float qmax, int8_t* __restrict__ Qt,
                                                            float* __restrict__ ErrT, float* __restrict__ loss,
-                                                           int prio) {
+                                                           int prio, SweepGroups sg) {
     qt_set_chain_prio(prio);
+    if (sg.n > 1) {
+        const int g = sweep_group_of(sg, blockIdx.x * ROWS);
+        U += (size_t)g * sg.bsU;
+        g_idx += (size_t)g * K;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Un = sm;                  // [BS][BS]   Un[i][j] = U[i1+i][i1+j], zero outside j>=i / cnt
     float* wl = sm + BS * BS;        // [BS cols][ROWS]
@@ -349,8 +367,13 @@ __global__ __launch_bounds__(QTHREADS) void sweep_quad_kernel(float* __restrict_
                                                               const int32_t* __restrict__ g_idx, int i1, int cnt,
                                                               float qmin, float qmax, int8_t* __restrict__ Qt,
                                                               float* __restrict__ ErrT, float* __restrict__ loss,
-                                                              int prio) {
+                                                              int prio, SweepGroups sg) {
     qt_set_chain_prio(prio);
+    if (sg.n > 1) {
+        const int g = sweep_group_of(sg, blockIdx.x * QROWS);
+        U += (size_t)g * sg.bsU;
+        g_idx += (size_t)g * K;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Up = sm;                      // [BS][QL][UP_P]
     float* dd = sm + BS * UP_C;          // [BS] diag, [BS] 1 / diag^2
@@ -453,10 +476,9 @@ extern "C" size_t qt_gptq_sweep_workspace_bytes(int R, int K, int blocksize) {
     return n;
 }
 
-extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float* scale_t, const float* zp_t, int G,
-                             const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt, float* loss,
-                             void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int sweep_run(float* W, int R, int K, const float* U, const float* scale_t, const float* zp_t, int G,
+                     const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt, float* loss, void* workspace,
+                     size_t workspace_bytes, hipStream_t stream, const SweepGroups& sg) {
     QT_CHECK_ARG(W && U && scale_t && zp_t && g_idx && Qt && loss, "qt_gptq_sweep: null pointer");
     QT_CHECK_ARG(R > 0 && K > 0 && G > 0, "qt_gptq_sweep: bad shape R=%d K=%d G=%d", R, K, G);
     QT_CHECK_ARG(blocksize == BS, "qt_gptq_sweep: blocksize=%d unsupported (this build: 128)", blocksize);
@@ -468,7 +490,7 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
         return QT_ERR_WORKSPACE;
     }
     float* ErrT = (float*)qt_align_up((size_t)workspace, 256);
-    const bool far3 = sweep_far_bf16x3(R, K);
+    const bool far3 = sweep_far_bf16x3(R, K) && sg.n <= 1;      // the opt-in three-plane far update: single problem only
     FarPlan fp{};
     unsigned short *Upl = nullptr, *Epl = nullptr;
     G3Item* far_tab = nullptr;
@@ -509,6 +531,13 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
         return b < 1 ? 1 : (b > SWEEP_MAX_BATCH ? SWEEP_MAX_BATCH : b);
     }();
     const int prio = qt_chain_prio();
+    // stacked problems: an update product's B operand (rows of U) depends on the row group of the output tile
+    auto set_groups = [&](SgemmArgs& g) {
+        if (sg.n <= 1) return;
+        g.n_groups = sg.n;
+        g.group_bsB = sg.bsU;
+        for (int i = 0; i < sg.n; ++i) g.group_m_end[i] = sg.row_end[i];
+    };
     if (far3) {
         // planes of U once (pad columns zeroed: edge tiles read them), the tile list once: column-major in tiles, so a
         // far update over the first Tn' tile columns right of the batch is a prefix of it
@@ -548,10 +577,10 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
             qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
             if (quad)
                 hipLaunchKernelGGL(sweep_quad_kernel, dim3((R + QROWS - 1) / QROWS), dim3(QTHREADS), QUAD_LDS, stream, W,
-                                   R, K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio);
+                                   R, K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio, sg);
             else
                 hipLaunchKernelGGL(sweep_block_kernel, dim3((R + ROWS - 1) / ROWS), dim3(ROWS), SWEEP_LDS, stream, W, R,
-                                   K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio);
+                                   K, U, scale_t, zp_t, g_idx, i1, cnt, qmin, qmax, Qt, err_blk, loss, prio, sg);
             qt_prof_mark(QT_PROF_SWEEP_BLOCK, stream);
             QT_LAUNCH_CHECK();
             if (i2 < bend) {   // near update: the rest of this batch
@@ -561,6 +590,7 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
                 g.Cin = W + i2; g.ldcin = K;
                 g.Cout = W + i2; g.ldcout = K;
                 g.M = R; g.N = bend - i2; g.kdim = cnt; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
+                set_groups(g);
                 const int rc = qt_sgemm_tn(g, stream);
                 if (rc) return rc;
             }
@@ -585,9 +615,41 @@ extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float
             g.Cout = W + bend; g.ldcout = K;
             g.M = R; g.N = K - bend; g.kdim = bend - b0; g.k_mode = SG_K_FULL; g.mode = SG_MODE_SUB;
             g.chain_len = BS;
+            set_groups(g);
             const int rc = qt_sgemm_tn(g, stream);
             if (rc) return rc;
         }
     }
     return QT_OK;
+}
+
+extern "C" int qt_gptq_sweep(float* W, int R, int K, const float* U, const float* scale_t, const float* zp_t, int G,
+                             const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt, float* loss,
+                             void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+    SweepGroups sg{};
+    return sweep_run(W, R, K, U, scale_t, zp_t, G, g_idx, blocksize, num_bits, Qt, loss, workspace, workspace_bytes,
+                     (hipStream_t)stream_, sg);
+}
+
+extern "C" int qt_gptq_sweep_grouped(float* W, int R, int K, const float* U, int64_t strideU, int n_groups,
+                                     const int32_t* row_end, const float* scale_t, const float* zp_t, int G,
+                                     const int32_t* g_idx, int blocksize, int num_bits, int8_t* Qt, float* loss,
+                                     void* workspace, size_t workspace_bytes, qt_stream_t stream_) {
+    QT_CHECK_ARG(n_groups >= 1 && n_groups <= SG_MAX_GROUPS && row_end, "qt_gptq_sweep_grouped: 1 <= n_groups <= %d", SG_MAX_GROUPS);
+    SweepGroups sg{};
+    sg.n = n_groups;
+    sg.bsU = strideU;
+    int prev = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        // 128: the update products' tile height (no tile may straddle two factors); the block kernels need 64
+        QT_CHECK_ARG(row_end[g] > prev && (row_end[g] % 128 == 0 || g == n_groups - 1),
+                     "qt_gptq_sweep_grouped: group %d ends at row %d (ascending; every boundary but the last a multiple of 128)", g,
+                     row_end[g]);
+        sg.row_end[g] = row_end[g];
+        prev = row_end[g];
+    }
+    QT_CHECK_ARG(prev == R, "qt_gptq_sweep_grouped: the last group ends at row %d, R = %d", prev, R);
+    QT_CHECK_ARG(n_groups == 1 || strideU >= (int64_t)K * K, "qt_gptq_sweep_grouped: strideU < K*K");
+    return sweep_run(W, R, K, U, scale_t, zp_t, G, g_idx, blocksize, num_bits, Qt, loss, workspace, workspace_bytes,
+                     (hipStream_t)stream_, sg);
 }

@@ -8,7 +8,7 @@ section 8a rows a7-a11, a14), which quantool reaches through
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -166,102 +166,175 @@ def gptq_quantize_shared(weights: Sequence[torch.Tensor], acc: HessianAccumulato
     ordering, dead columns, damping, factorisation, block sweep; the rows of all weights are
     swept as one stacked matrix (rows are independent given U).
     """
-    if acc.n <= 0:
-        raise ValueError("no calibration samples were accumulated for this Linear")
+    return gptq_quantize_batched([(weights, acc)], qargs, block_size=block_size, dampening_frac=dampening_frac,
+                                 scale_dtype=scale_dtype, keeps=None if keep is None else [keep])[0]
+
+
+def batch_chains_enabled() -> bool:
+    """``QT_BATCH_CHAINS=0``: every Linear group through its own chain on its own stream (rounds 1-3; A/B runs and
+    cross-checks -- the results are the same to the bit either way)."""
+    import os
+
+    return os.environ.get("QT_BATCH_CHAINS", "1") != "0"
+
+
+def batchable(groups: Sequence[Tuple[Sequence[torch.Tensor], HessianAccumulator]]) -> List[List[int]]:
+    """Indices of ``groups`` (Linear groups = weights sharing one accumulator) that can go through the chain together:
+    equal in_features, at most ``ops.MAX_BATCH`` per batch, and -- because no 128-row tile of the stacked sweep may
+    straddle two factors -- at most ONE group per batch whose row count is not a multiple of 128 (it goes last)."""
+    by_k = {}
+    for i, (ws, acc) in enumerate(groups):
+        by_k.setdefault(acc.K, []).append(i)
+    out = []
+    for K, idx in by_k.items():
+        aligned = [i for i in idx if sum(int(w.shape[0]) for w in groups[i][0]) % 128 == 0]
+        ragged = [i for i in idx if i not in aligned]
+        while aligned or ragged:
+            take = aligned[:ops.MAX_BATCH - 1] if ragged else aligned[:ops.MAX_BATCH]
+            aligned = aligned[len(take):]
+            if ragged and len(take) < ops.MAX_BATCH:
+                take.append(ragged.pop(0))
+            out.append(take)
+    return out
+
+
+def gptq_quantize_batched(groups: Sequence[Tuple[Sequence[torch.Tensor], HessianAccumulator]], qargs: QuantArgs, *,
+                          block_size: int = 128, dampening_frac: float = 0.01,
+                          scale_dtype: Optional[torch.dtype] = None,
+                          keeps: Optional[List[dict]] = None) -> List[List[GPTQResult]]:
+    """``gptq_quantize_shared`` for several Linear groups of ONE in_features at once (``batchable`` says which): the
+    groups' factorisations go through ``qt_cholesky_inverse_upper_batched`` (one chain of launches for all of them) and
+    their rows through one stacked ``qt_gptq_sweep_grouped`` (rows know their group's factor).  Upstream quantises every
+    Linear of a decoder layer inside one ``oneshot`` call (base.py:161); per group the results are BIT-IDENTICAL to
+    ``gptq_quantize_shared`` (``tests/test_gpu_batched_chains.py``).  One group: the single-problem entry points."""
+    n = len(groups)
+    if n == 0:
+        return []
     if int(block_size) != 128:
         # the sweep kernel keeps one 128-column block of U and W in LDS; a different block size changes
         # which updates are two-rounding rank-1 steps and which are the fma chain of the trailing
         # product, i.e. the bits -- refuse instead of silently using 128
         raise ValueError(f"block_size={block_size}: this backend implements upstream's default block_size=128 only")
-    K = acc.K
-    dev = acc.G.device
+    K = groups[0][1].K
+    dev = groups[0][1].G.device
+    for ws, acc in groups:
+        if acc.n <= 0:
+            raise ValueError("no calibration samples were accumulated for this Linear")
+        if acc.K != K:
+            raise ValueError(f"batched groups must share in_features ({acc.K} != {K})")
+        for w in ws:
+            if w.dim() != 2 or w.shape[1] != K:
+                raise ValueError(f"weight shape {tuple(w.shape)} does not match in_features {K}")
+    if n > ops.MAX_BATCH:
+        raise ValueError(f"at most {ops.MAX_BATCH} groups per batch (see batchable())")
     actorder = _normalize_actorder(qargs.actorder)
     gs = qargs.kernel_group_size
     gsz = K if gs <= 0 else gs
     if K % gsz:
         raise ValueError(f"in_features {K} not divisible by group_size {gsz}")
     G = K // gsz
-    for w in weights:
-        if w.dim() != 2 or w.shape[1] != K:
-            raise ValueError(f"weight shape {tuple(w.shape)} does not match in_features {K}")
-    rows = [int(w.shape[0]) for w in weights]
-    R = sum(rows)
-
-    # ---- activation ordering (a9): perm = argsort(diag H, descending) --------------------
-    perm = inv = None   # perm: sweep position -> original column; inv: its inverse
-    if actorder is not None:
-        diag = ops.hessian_diag(acc.G, acc.n)
-        perm, inv = ops.argsort_desc(diag)
+    rows = [[int(w.shape[0]) for w in ws] for ws, _ in groups]
+    grp_rows = [sum(r) for r in rows]
+    if any(r % 128 for r in grp_rows[:-1]):
+        raise ValueError(f"stacked groups of {grp_rows} rows: every group but the last needs a multiple of 128 (batchable())")
+    R = sum(grp_rows)
+    row_end = [sum(grp_rows[:i + 1]) for i in range(n)]
+    row_begin = [0] + row_end[:-1]
     ar = torch.arange(K, dtype=torch.int32, device=dev)
     g_orig = (ar // gsz).to(torch.int32)
 
-    # ---- prepare + factorise once for all sharers (a8) -----------------------------------
-    ubuf = ops.factor_buffer(K, dev)        # U's storage doubles as prepare's scratch (no K x K workspace kept per stream)
-    A, dead, _ = ops.hessian_prepare(acc.G, acc.n, dampening_frac, perm, scratch=ubuf)
-    U, info = ops.cholesky_inverse_upper(A, U_out=ops.factor_view(ubuf, K))
+    # ---- per group: activation ordering (a9), prepare (a8) into its slice of the batch -----------------
+    # U's storage doubles as prepare's scratch (no K x K workspace kept per stream); +256 floats per problem
+    ubuf = torch.empty((n, K * K + 256), dtype=torch.float32, device=dev)
+    U = ubuf[:, :K * K].view(n, K, K)
+    A = torch.empty((n, K, K), dtype=torch.float32, device=dev)
+    perms, invs, deads = [], [], []
+    for b, (ws, acc) in enumerate(groups):
+        perm = inv = None   # perm: sweep position -> original column; inv: its inverse
+        if actorder is not None:
+            perm, inv = ops.argsort_desc(ops.hessian_diag(acc.G, acc.n))
+        _, dead, _ = ops.hessian_prepare(acc.G, acc.n, dampening_frac, perm, A_out=A[b], scratch=ubuf[b])
+        perms.append(perm)
+        invs.append(inv)
+        deads.append(dead)
+
+    # ---- factorise all groups in one chain of launches (a8) -------------------------------------------
+    if n == 1:
+        _, info = ops.cholesky_inverse_upper(A[0], U_out=U[0])
+    else:
+        info = ops.cholesky_inverse_upper_batched(A, U)
     del A
 
-    # ---- stacked fp32 working copy in sweep order, observer (a10) ------------------------
+    # ---- stacked fp32 working copy in sweep order, observer (a10) ------------------------------------
     Wf = torch.empty((R, K), dtype=torch.float32, device=dev)
     scale = torch.empty((R, G), dtype=torch.float32, device=dev)
     zp = torch.empty((R, G), dtype=torch.float32, device=dev)
-    scale_t = torch.empty((G, R), dtype=torch.float32, device=dev)
-    zp_t = torch.empty((G, R), dtype=torch.float32, device=dev)
-    r0 = 0
-    for w, r in zip(weights, rows):
-        if w.stride(1) != 1:
-            w = w.contiguous()
-        ops.weight_gather_f32(w, perm, dead, out=Wf[r0:r0 + r])
-        r0 += r
-    if actorder == "group":
-        # qparams on the permuted matrix; groups are runs of 128 sweep positions
-        s_, z_, st_, zt_ = ops.group_minmax_qparams(Wf, gs, qargs.symmetric, qargs.num_bits)
-        scale, zp, scale_t, zp_t = s_, z_, st_, zt_
-        g_sweep = g_orig
-    else:
-        # qparams on the ORIGINAL matrix (before permutation / dead-column zeroing)
-        r0 = 0
-        for w, r in zip(weights, rows):
-            s_, z_, _, _ = ops.group_minmax_qparams(w if w.stride(1) == 1 else w.contiguous(), gs,
-                                                    qargs.symmetric, qargs.num_bits)
-            scale[r0:r0 + r] = s_
-            zp[r0:r0 + r] = z_
+    g_sweeps = []
+    for b, (ws, acc) in enumerate(groups):
+        r0 = row_begin[b]
+        for w, r in zip(ws, rows[b]):
+            if w.stride(1) != 1:
+                w = w.contiguous()
+            ops.weight_gather_f32(w, perms[b], deads[b], out=Wf[r0:r0 + r])
             r0 += r
-        scale_t.copy_(scale.t())
-        zp_t.copy_(zp.t())
-        g_sweep = g_orig if perm is None else g_orig[perm.long()].contiguous()
+        if actorder == "group":
+            # qparams on the permuted matrix; groups are runs of 128 sweep positions
+            s_, z_, _, _ = ops.group_minmax_qparams(Wf[row_begin[b]:row_end[b]], gs, qargs.symmetric, qargs.num_bits)
+            scale[row_begin[b]:row_end[b]] = s_
+            zp[row_begin[b]:row_end[b]] = z_
+            g_sweeps.append(g_orig)
+        else:
+            # qparams on the ORIGINAL matrix (before permutation / dead-column zeroing)
+            r0 = row_begin[b]
+            for w, r in zip(ws, rows[b]):
+                s_, z_, _, _ = ops.group_minmax_qparams(w if w.stride(1) == 1 else w.contiguous(), gs,
+                                                        qargs.symmetric, qargs.num_bits)
+                scale[r0:r0 + r] = s_
+                zp[r0:r0 + r] = z_
+                r0 += r
+            g_sweeps.append(g_orig if perms[b] is None else g_orig[perms[b].long()].contiguous())
+    scale_t = scale.t().contiguous()
+    zp_t = zp.t().contiguous()
 
-    # ---- the sweep (a11) ------------------------------------------------------------------
-    if keep is not None:  # stage boundaries for the parity tests
-        keep.update(U=U.clone(), perm=perm, dead=dead)
-    Qt, loss = ops.gptq_sweep(Wf, U, scale_t, zp_t, g_sweep, block_size, qargs.num_bits)
-    del Wf, U
-
-    # ---- outputs in original column order (a14) -------------------------------------------
-    col_src = inv  # output column c lives at sweep position inv[c]
-    if actorder == "group":
-        g_of_col = g_sweep[inv.long()].contiguous()     # upstream's saved weight_g_idx
+    # ---- the sweep (a11): all groups' rows at once, each row against its group's factor --------------
+    if keeps is not None:  # stage boundaries for the parity tests
+        for b in range(n):
+            keeps[b].update(U=U[b].clone(), perm=perms[b], dead=deads[b])
+    if n == 1:
+        Qt, loss = ops.gptq_sweep(Wf, U[0], scale_t, zp_t, g_sweeps[0], block_size, qargs.num_bits)
     else:
-        g_of_col = g_orig
-    out: List[GPTQResult] = []
-    r0 = 0
-    for w, r in zip(weights, rows):
-        Qt_i = Qt[:, r0:r0 + r].contiguous() if len(rows) > 1 else Qt
-        sdt = scale_dtype or (w.dtype if w.dtype in (torch.bfloat16, torch.float16) else torch.float32)
-        sc_i = scale[r0:r0 + r].contiguous()
-        zp_i = zp[r0:r0 + r].contiguous()
-        packed = ops.pack_int4(Qt_i, col_src) if qargs.num_bits == 4 else None
-        wq = None
-        if packed is None:
-            wq = (Qt_i.t() if col_src is None else Qt_i[col_src.long()].t()).contiguous()
-        out.append(GPTQResult(
-            weight_packed=packed, weight_q=wq, weight_scale=sc_i.to(sdt),
-            weight_zero_point=None if qargs.symmetric else zp_i.to(torch.int8),
-            weight_g_idx=g_of_col if actorder == "group" else None,
-            weight_shape=torch.tensor([r, K], dtype=torch.int64), loss=loss[r0:r0 + r], info=info,
-            scale_f32=sc_i, zp_f32=zp_i, Qt=Qt_i, col_src=col_src, g_of_col=g_of_col))
-        r0 += r
-    return out
+        Qt, loss = ops.gptq_sweep_grouped(Wf, U, row_end, scale_t, zp_t, torch.stack(g_sweeps).contiguous(), block_size,
+                                          qargs.num_bits)
+    del Wf, U, ubuf
+
+    # ---- outputs in original column order (a14) -------------------------------------------------------
+    results: List[List[GPTQResult]] = []
+    for b, (ws, acc) in enumerate(groups):
+        col_src = invs[b]  # output column c lives at sweep position inv[c]
+        if actorder == "group":
+            g_of_col = g_sweeps[b][invs[b].long()].contiguous()     # upstream's saved weight_g_idx
+        else:
+            g_of_col = g_orig
+        out: List[GPTQResult] = []
+        r0 = row_begin[b]
+        for w, r in zip(ws, rows[b]):
+            Qt_i = Qt[:, r0:r0 + r].contiguous() if R > r else Qt
+            sdt = scale_dtype or (w.dtype if w.dtype in (torch.bfloat16, torch.float16) else torch.float32)
+            sc_i = scale[r0:r0 + r].contiguous()
+            zp_i = zp[r0:r0 + r].contiguous()
+            packed = ops.pack_int4(Qt_i, col_src) if qargs.num_bits == 4 else None
+            wq = None
+            if packed is None:
+                wq = (Qt_i.t() if col_src is None else Qt_i[col_src.long()].t()).contiguous()
+            out.append(GPTQResult(
+                weight_packed=packed, weight_q=wq, weight_scale=sc_i.to(sdt),
+                weight_zero_point=None if qargs.symmetric else zp_i.to(torch.int8),
+                weight_g_idx=g_of_col if actorder == "group" else None,
+                weight_shape=torch.tensor([r, K], dtype=torch.int64), loss=loss[r0:r0 + r], info=info[b:b + 1],
+                scale_f32=sc_i, zp_f32=zp_i, Qt=Qt_i, col_src=col_src, g_of_col=g_of_col))
+            r0 += r
+        results.append(out)
+    return results
 
 
 def gptq_quantize_linear(weight: torch.Tensor, acc: HessianAccumulator, qargs: QuantArgs, **kw) -> GPTQResult:

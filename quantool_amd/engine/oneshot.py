@@ -21,7 +21,8 @@ from typing import Any, Dict, Iterable, List, Optional, Tuple
 import torch
 
 from ..hip import ops
-from .gptq_linear import HessianAccumulator, gptq_quantize_shared
+from .gptq_linear import (HessianAccumulator, batch_chains_enabled, batchable, gptq_quantize_batched,
+                          gptq_quantize_shared)
 from .modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
 
 logger = logging.getLogger(__name__)
@@ -254,7 +255,16 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
                 return all(isinstance(t, torch.Tensor) and t.numel() // max(1, t.shape[-1]) >= HessianAccumulator.DIRECT_TOKENS
                            for t in a)
 
+            def chain_phase_batched(states):
+                """Groups of equal in_features through one chain of launches (gptq_quantize_batched; bit-identical per
+                group to chain_phase)."""
+                res = gptq_quantize_batched([(ws, acc) for _, _, ws, acc in states], qargs, block_size=gp.block_size,
+                                            dampening_frac=gp.dampening_frac)
+                for (_, names, _, _), rs in zip(states, res):
+                    results.update(dict(zip(names, rs)))
+
             pool = GroupStreams(device)
+            behind_gram = []      # (state, event): chains whose Gram sum runs on the Gram stream
             for g in sorted(order, key=lambda g: int(next(iter(g.weights.values())).shape[1])):
                 if not long_batches(g):
                     def both(g=g):
@@ -264,9 +274,23 @@ def _oneshot_linears(cal: LinearCalibrationSet, recipe, device) -> QuantizedLine
                     pool.run(both)
                     continue
                 state, ready = pool.run_gram(lambda g=g: gram_phase(g))
-                if state is not None:      # issued right behind its Gram sum: the host never runs a layer ahead
+                if state is None:
+                    continue
+                if batch_chains_enabled():
+                    behind_gram.append((state, ready))
+                else:                      # issued right behind its Gram sum: the host never runs a layer ahead
                     pool.run(lambda state=state: chain_phase(state), after=ready,
                              tensors=[state[3].G] + list(state[2]))
+            # the groups of equal in_features share one batched factorisation and one stacked sweep, on one stream
+            # behind the Gram sums of all of them
+            for idx in batchable([(st[2], st[3]) for st, _ in behind_gram]):
+                members = [behind_gram[i] for i in idx]
+                states = [st for st, _ in members]
+                tensors = [t for st in states for t in [st[3].G] + list(st[2])]
+                if len(states) == 1:
+                    pool.run(lambda state=states[0]: chain_phase(state), after=members[0][1], tensors=tensors)
+                else:
+                    pool.run(lambda states=states: chain_phase_batched(states), after=[ev for _, ev in members], tensors=tensors)
             pool.join()
         mod = gp
     else:

@@ -19,7 +19,8 @@ from typing import Any, Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from .gptq_linear import HessianAccumulator, gptq_quantize_shared
+from .gptq_linear import (HessianAccumulator, batch_chains_enabled, batchable, gptq_quantize_batched,
+                          gptq_quantize_shared)
 from .modifiers import AWQModifier, GPTQModifier, SmoothQuantModifier
 from .streams import GroupStreams
 
@@ -528,11 +529,37 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                     linears[n].weight.data.copy_(r.dequantized(linears[n].weight.dtype))
                     results[n] = r
 
-            for lead, names in sorted(leaders.items(), key=lambda kv: (-linears[kv[0]].in_features, kv[0])):
-                if pool is not None:
-                    pool.run(lambda lead=lead, names=names: quantize_group(lead, names))
-                else:
-                    quantize_group(lead, names)
+            def quantize_batch(leads):
+                """Input groups of equal in_features through ONE chain of launches (gptq_quantize_batched): a Llama
+                layer's q/k/v + o + gate/up, a sparse-MoE layer's experts.  Per group bit-identical to quantize_group."""
+                keeps = [{} for _ in leads] if DEBUG_KEEP is not None else None
+                res = gptq_quantize_batched([([linears[n].weight.data for n in leaders[lead]], accs[lead]) for lead in leads],
+                                            qargs, block_size=gp.block_size, dampening_frac=gp.dampening_frac, keeps=keeps)
+                for i, lead in enumerate(leads):
+                    if keeps is not None:
+                        DEBUG_KEEP[lead] = dict(keeps[i], names=list(leaders[lead]), n=accs[lead].n, G=accs[lead].G.clone())
+                    for n, r in zip(leaders[lead], res[i]):
+                        linears[n].weight.data.copy_(r.dequantized(linears[n].weight.dtype))
+                        results[n] = r
+
+            by_size = sorted(leaders.items(), key=lambda kv: (-linears[kv[0]].in_features, kv[0]))
+            if pool is not None and batch_chains_enabled():
+                live = [lead for lead, _ in by_size if accs[lead].n > 0]
+                for lead, names in by_size:
+                    if accs[lead].n == 0:
+                        pool.run(lambda lead=lead, names=names: quantize_group(lead, names))      # the RTN fallback
+                for idx in batchable([([linears[n].weight.data for n in leaders[lead]], accs[lead]) for lead in live]):
+                    leads = [live[i] for i in idx]
+                    if len(leads) == 1:
+                        pool.run(lambda lead=leads[0]: quantize_group(lead, leaders[lead]))
+                    else:
+                        pool.run(lambda leads=leads: quantize_batch(leads))
+            else:
+                for lead, names in by_size:
+                    if pool is not None:
+                        pool.run(lambda lead=lead, names=names: quantize_group(lead, names))
+                    else:
+                        quantize_group(lead, names)
             if pool is not None:
                 pool.join()
             accs.clear()

@@ -52,14 +52,14 @@ class GroupStreams:
 
     def run(self, fn: Callable[[], object], after=None, tensors=()):
         """Run ``fn`` with the next side stream current.  What ``fn`` enqueues starts after everything
-        already on the main stream (and after the event ``after``) and is waited for by ``join``.
+        already on the main stream (and after the event -- or list of events -- ``after``) and is waited for by ``join``.
         ``tensors``: allocated on another stream (the Gram stream) and read by ``fn`` -- recorded on this
         one so that the caching allocator does not hand their memory out while ``fn``'s kernels run."""
         st = self.streams[self._next % len(self.streams)]
         self._next += 1
         st.wait_stream(self.main)
-        if after is not None:
-            st.wait_event(after)
+        for ev in ([] if after is None else (after if isinstance(after, (list, tuple)) else [after])):
+            st.wait_event(ev)
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(st)

@@ -48,6 +48,8 @@ SIGNATURES = {
     "qt_gptq_sweep_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "qt_gptq_sweep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "qt_gptq_sweep_grouped": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "qt_pack_int4": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "qt_awq_weight_mean_workspace_bytes": (c_size_t, [c_int, c_int]),
     "qt_awq_weight_mean_accumulate": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p, c_void_p,

@@ -361,6 +361,41 @@ def gptq_sweep(W: torch.Tensor, U: torch.Tensor, scale_t: torch.Tensor, zp_t: to
     return Qt, loss
 
 
+def gptq_sweep_grouped(W: torch.Tensor, U: torch.Tensor, row_end, scale_t: torch.Tensor, zp_t: torch.Tensor,
+                       g_idx: torch.Tensor, blocksize: int = 128, num_bits: int = 4):
+    """Several Linear groups of one in_features as ONE stacked sweep.  W fp32 [R_total, K] (in place), U [n, K, K] (its
+    [g] slices contiguous K x K at a uniform stride), ``row_end``: list of n cumulative row counts (every boundary but
+    the last a multiple of 128), g_idx int32 [n, K].  Returns (Qt int8 [K, R_total], loss fp32 [R_total])."""
+    import ctypes
+
+    lib = load()
+    _req(W, torch.float32, "W", 2)
+    _req(U, torch.float32, "U", 3)
+    _req(scale_t, torch.float32, "scale_t", 2)
+    _req(zp_t, torch.float32, "zp_t", 2)
+    _req(g_idx, torch.int32, "g_idx", 2)
+    R, K = W.shape
+    n = U.shape[0]
+    G = scale_t.shape[0]
+    row_end = [int(r) for r in row_end]
+    if not (W.is_contiguous() and scale_t.is_contiguous() and zp_t.is_contiguous() and g_idx.is_contiguous()):
+        raise ValueError("all sweep operands must be contiguous")
+    if (tuple(U.shape) != (n, K, K) or U.stride(2) != 1 or U.stride(1) != K or scale_t.shape != (G, R) or zp_t.shape != (G, R)
+            or tuple(g_idx.shape) != (n, K) or len(row_end) != n or not (1 <= n <= MAX_BATCH)):
+        raise ValueError("grouped sweep operand shapes inconsistent")
+    if row_end[-1] != R or any(b <= a for a, b in zip([0] + row_end[:-1], row_end)) or any(r % 128 for r in row_end[:-1]):
+        raise ValueError(f"row_end={row_end}: ascending, every boundary but the last a multiple of 128, last == R ({R})")
+    Qt = torch.empty((K, R), dtype=torch.int8, device=W.device)
+    loss = torch.empty(R, dtype=torch.float32, device=W.device)
+    ws = workspace(lib.qt_gptq_sweep_workspace_bytes(R, K, blocksize), W.device, "sweep")
+    ends = (ctypes.c_int32 * n)(*row_end)
+    check("qt_gptq_sweep_grouped", lib.qt_gptq_sweep_grouped(
+        W.data_ptr(), R, K, U.data_ptr(), U.stride(0) if n > 1 else K * K, n, ctypes.cast(ends, ctypes.c_void_p),
+        scale_t.data_ptr(), zp_t.data_ptr(), G, g_idx.data_ptr(), blocksize, num_bits, Qt.data_ptr(), loss.data_ptr(),
+        ws.data_ptr(), ws.numel(), _stream()))
+    return Qt, loss
+
+
 # ---- a14 ----------------------------------------------------------------------------------
 def pack_int4(Qt: torch.Tensor, col_src: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = load()

@@ -1,0 +1,19 @@
+"""Host logic of the batched chains: which Linear groups of a layer go through the chain together
+(``engine.gptq_linear.batchable``; GPU side: tests/test_gpu_batched_chains.py)."""
+import torch
+
+
+def test_batchable_splits_by_in_features_and_keeps_one_ragged_group_per_batch():
+    from quantool_amd.engine.gptq_linear import batchable
+
+    class Acc:
+        def __init__(self, K):
+            self.K = K
+
+    def grp(K, r):
+        return ([torch.empty((r, K), device="meta")], Acc(K))
+
+    groups = [grp(512, 128), grp(256, 64), grp(512, 100), grp(512, 72), grp(256, 128), grp(512, 256)]
+    assert batchable(groups) == [[0, 5, 2], [3], [4, 1]]
+    many = [grp(128, 128) for _ in range(19)]
+    assert [len(b) for b in batchable(many)] == [16, 3]

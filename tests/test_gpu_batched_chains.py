@@ -64,3 +64,50 @@ def test_batched_factorisation_reports_a_bad_pivot_per_problem(dev):
     assert torch.equal(Ub[1], torch.eye(K, device=dev))      # upstream's LinAlgError fallback, for that problem only
     for b in (0, 2):
         assert torch.equal(Ub[b], want[b][0])
+
+
+def _group(dev, K, row_counts, n_tokens, seed, dtype=torch.bfloat16):
+    from quantool_amd.engine.gptq_linear import HessianAccumulator
+
+    g = torch.Generator(device=dev).manual_seed(seed)
+    X = torch.randn((n_tokens, K), generator=g, device=dev)
+    X[:, torch.randperm(K, generator=g, device=dev)[: max(1, K // 50)]] *= 8.0
+    acc = HessianAccumulator(K, dev)
+    acc.add(X.to(dtype).reshape(4, n_tokens // 4, K))
+    ws = [(torch.randn((r, K), generator=g, device=dev) * 0.02).to(dtype) for r in row_counts]
+    return ws, acc
+
+
+def _same(a, b):
+    return (a is None and b is None) or (a is not None and b is not None and torch.equal(a, b))
+
+
+@pytest.mark.parametrize("actorder,symmetric,bits", [("static", True, 4), (None, True, 4), ("group", False, 4), ("static", True, 8)])
+def test_batched_groups_equal_their_single_group_runs_bit_for_bit(dev, actorder, symmetric, bits):
+    """Three Linear groups of one in_features (two Linears, one Linear, and a ragged 200-row one that must go last),
+    different Hessians: factorised in one batched chain, swept as one stacked matrix -- every output of every Linear equal
+    to what ``gptq_quantize_shared`` gives for its group alone."""
+    from quantool_amd.engine.gptq_linear import batchable, gptq_quantize_batched, gptq_quantize_shared
+    from quantool_amd.engine.schemes import QuantArgs
+
+    K = 640
+    qa = QuantArgs(num_bits=bits, symmetric=symmetric, group_size=128 if bits == 4 else None,
+                   strategy="group" if bits == 4 else "channel", actorder=actorder)
+    groups = [_group(dev, K, [200], 2048, seed=3), _group(dev, K, [128, 256], 1536, seed=1), _group(dev, K, [256], 4096, seed=2)]
+    order = batchable(groups)
+    assert order == [[1, 2, 0]]                       # the ragged group last
+    batch = [groups[i] for i in order[0]]
+    keeps = [{} for _ in batch]
+    got = gptq_quantize_batched(batch, qa, keeps=keeps)
+    torch.cuda.synchronize()
+    for (ws, acc), res, kp in zip(batch, got, keeps):
+        k1 = {}
+        want = gptq_quantize_shared(ws, acc, qa, keep=k1)
+        torch.cuda.synchronize()
+        assert torch.equal(kp["U"], k1["U"]) and _same(kp["perm"], k1["perm"]) and torch.equal(kp["dead"], k1["dead"])
+        assert len(res) == len(want) == len(ws)
+        for r, w in zip(res, want):
+            for f in ("weight_packed", "weight_q", "weight_scale", "weight_zero_point", "weight_g_idx", "loss", "Qt",
+                      "scale_f32", "zp_f32", "info"):
+                assert _same(getattr(r, f), getattr(w, f)), f
+            assert torch.equal(r.dequantized(), w.dequantized()) and r.weight_shape.tolist() == w.weight_shape.tolist()
