@@ -122,6 +122,9 @@ def smooth_group(lins, weights, X, norm_vec, alpha=0.5):
 # pass beside them, and the reverse); the printed line is labelled "diagnostic" and is not a measurement of the metric.
 SKIP = os.environ.get("QT_BENCH_SKIP", "")
 BATCH_CHAINS = os.environ.get("QT_BATCH_CHAINS", "1") != "0"
+# QT_BENCH_SHAPE_SCALE=d: every width of the model's layer divided by d (multiples of 128) -- control-flow rehearsals of
+# configs[3] / configs[4] with N ranks on one GPU (tests/test_gpu_bench_rehearsal.py); the line is labelled, not a result.
+SHAPE_SCALE = int(os.environ.get("QT_BENCH_SHAPE_SCALE", "1") or 1)
 _DIAG_G = {}
 
 
@@ -509,6 +512,10 @@ def main():
 
     lib = _lib.load()  # raises if the HIP library is missing: there is no fallback
     shape = MODEL_SHAPES[args.model]
+    if SHAPE_SCALE > 1:      # rehearsal of a big configuration's control flow at 1 / SHAPE_SCALE of its widths
+        from quantool_amd.engine.model_shapes import scaled
+
+        shape = scaled(shape, SHAPE_SCALE)
     if args.method == "awq" and args.model != "llama-3-8b":
         raise SystemExit("--method awq is BASELINE.json configs[2]: Llama-3-8B only")
     n_tokens = args.samples * SEQ_LEN
@@ -524,7 +531,7 @@ def main():
         top2 = torch.randn((n_tokens, 8), generator=g, device=dev).topk(2, dim=1).indices
         route = [torch.nonzero((top2 == e).any(dim=1)).flatten() for e in range(8)]
         route_counts = [int(r.numel()) for r in route]
-        x_moe = synth_activations(n_tokens, 4096, seed=5 + 1000 * rank, device=dev)
+        x_moe = synth_activations(n_tokens, shape.groups[0][1], seed=5 + 1000 * rank, device=dev)
     for gi, (gname, K, lins) in enumerate(shape.groups):
         if gname.startswith("expert"):
             e = int(gname[len("expert"):].split("_")[0])
@@ -542,7 +549,7 @@ def main():
         # only; experts are quantised un-smoothed)
         g = torch.Generator(device=dev)
         g.manual_seed(11)
-        smooth = {"attn_in": (1.0 + 0.1 * torch.randn(4096, generator=g, device=dev)).to(torch.bfloat16)}
+        smooth = {"attn_in": (1.0 + 0.1 * torch.randn(shape.groups[0][1], generator=g, device=dev)).to(torch.bfloat16)}
     torch.cuda.synchronize()
 
     def barrier():
@@ -696,6 +703,8 @@ def main():
                         f"1 decoder layer (7 Linears, {wpl} weights) per step per GPU")
         if SKIP:
             metric = f"DIAGNOSTIC (QT_BENCH_SKIP={SKIP}: half of the step left out) -- not a measurement of: " + metric
+        if SHAPE_SCALE > 1:
+            metric = f"REHEARSAL (QT_BENCH_SHAPE_SCALE={SHAPE_SCALE}: layer widths divided) -- not a measurement of: " + metric
         line = {
             "metric": metric,
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -57,3 +57,18 @@ MODEL_SHAPES: Dict[str, LayerShape] = {
         ("fc2_in", 3072, (("fc2", 768),)),
     )),
 }
+
+
+def scaled(shape: LayerShape, divisor: int) -> LayerShape:
+    """The same layer with every in / out width divided by ``divisor`` (kept a multiple of 128, at least 128): the
+    N-rank control flow of a big configuration (which groups exist, which are split over ranks, how many Linears the
+    final gather carries, ragged expert routing) at a size a one-GPU rehearsal finishes in seconds.  Not a benchmark
+    workload -- ``bench.py`` labels such a line."""
+    if divisor <= 1:
+        return shape
+
+    def dim(x: int) -> int:
+        return max(128, x // divisor // 128 * 128)
+
+    return LayerShape(f"{shape.name}/{divisor}", shape.n_layers,
+                      tuple((g, dim(K), tuple((n, dim(R)) for n, R in lins)) for g, K, lins in shape.groups))

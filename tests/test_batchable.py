@@ -17,3 +17,16 @@ def test_batchable_splits_by_in_features_and_keeps_one_ragged_group_per_batch():
     assert batchable(groups) == [[0, 5, 2], [3], [4, 1]]
     many = [grp(128, 128) for _ in range(19)]
     assert [len(b) for b in batchable(many)] == [16, 3]
+
+
+def test_scaled_shapes_keep_the_group_structure():
+    from quantool_amd.engine.model_shapes import MODEL_SHAPES, scaled
+
+    for name in ("llama-3-70b", "mixtral-8x7b"):
+        big, small = MODEL_SHAPES[name], scaled(MODEL_SHAPES[name], 16)
+        assert [g for g, _, _ in big.groups] == [g for g, _, _ in small.groups]
+        assert [[n for n, _ in lins] for _, _, lins in big.groups] == [[n for n, _ in lins] for _, _, lins in small.groups]
+        for (_, K, lins), (_, k, slins) in zip(big.groups, small.groups):
+            assert k == max(128, K // 16 // 128 * 128) and k % 128 == 0
+            assert all(r % 128 == 0 and r >= 128 for _, r in slins)
+    assert scaled(MODEL_SHAPES["llama-3-8b"], 1) is MODEL_SHAPES["llama-3-8b"]
