@@ -447,7 +447,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-split", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the layer's groups on one stream")
-    ap.add_argument("--lanes", type=int, default=2, help="layers in flight (independent stream sets)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="layers in flight (independent stream sets); 0 = 3 for the Llama-3-8B layer, 2 for the larger "
+                         "ones (round 4, batched chains: 8B 79.0 / 74.6 / 75.6 ms per step at 2 / 3 / 4 lanes on one box; "
+                         "a third Mixtral layer in flight does not fit next to its 27 GB of batched workspaces)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--launch-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--model", choices=["llama-3-8b", "llama-3-70b", "mixtral-8x7b"], default="llama-3-8b",
@@ -468,6 +471,8 @@ def main():
         # started without a launcher: become the launcher (nothing has touched the GPU yet)
         raise SystemExit(launch_ranks(args.gpus))
 
+    if args.lanes <= 0:
+        args.lanes = 3 if args.model == "llama-3-8b" else 2
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

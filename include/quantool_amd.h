@@ -132,6 +132,15 @@ int qt_group_minmax_qparams(const void* W, int w_dtype, int R, int K, int64_t ld
 int qt_weight_gather_f32(const void* W, int w_dtype, int R, int K, int64_t ldw, const int32_t* perm,
                          const uint8_t* dead, float* W_f32, qt_stream_t stream);
 
+/* Both of the above in ONE pass over W (static / no activation ordering, where the observer sees the ORIGINAL columns
+ * and the sweep's working copy is in sweep order): scale, zp [R, G] and W_f32 [R, K] as qt_group_minmax_qparams and
+ * qt_weight_gather_f32 give them, to the bit; scale_t / zp_t (may be NULL) at [g * ld_t + r] -- ld_t >= R lets a caller
+ * write a Linear's columns of a table that spans the stacked rows of several Linears.  A row must fit the LDS
+ * (K <= 81920 16-bit or 40960 fp32 elements). */
+int qt_weight_gather_qparams(const void* W, int w_dtype, int R, int K, int64_t ldw, const int32_t* perm,
+                             const uint8_t* dead, int group_size, int symmetric, int num_bits, float* W_f32, float* scale,
+                             float* zp, float* scale_t, float* zp_t, int64_t ld_t, qt_stream_t stream);
+
 /* ---- a11  the column sweep of quantize_weight -----------------------------------------------
  * W[R,K] fp32 in sweep order (updated in place: error-compensated, then dequantised values),
  * U[K,K] upper factor, scale_t/zp_t [G,R] fp32 (group-major, see qt_group_minmax_qparams),

@@ -70,6 +70,85 @@ __global__ __launch_bounds__(256) void gather_f32_kernel(const void* __restrict_
     out[(size_t)r * K + s] = v;
 }
 
+// One read of W for the observer AND the sweep's working copy (static / no activation ordering: qparams on the
+// ORIGINAL columns, working copy in sweep order): a workgroup takes one row into LDS (in its own dtype), the four waves
+// reduce its groups (wave per group, shuffles), then the row goes out permuted, widened to fp32, dead positions zeroed.
+// Same values as qparams_kernel + gather_f32_kernel (min / max are order-free, the scale arithmetic is the same code).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_qparams_kernel(const T* __restrict__ W, int dtype, int R, int K, int64_t ldw,
+                                                             const int32_t* __restrict__ perm,
+                                                             const uint8_t* __restrict__ dead, int gs, int symmetric,
+                                                             float qmin, float qmax, float* __restrict__ out,
+                                                             float* __restrict__ scale, float* __restrict__ zp,
+                                                             float* __restrict__ scale_t, float* __restrict__ zp_t,
+                                                             int64_t ld_t) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* row = (T*)smem;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* src = W + (size_t)r * ldw;
+    constexpr int V = 16 / sizeof(T);                    // elements per 16-byte load
+    if ((((uintptr_t)src) & 15) == 0 && K % V == 0) {
+        for (int c = tid * V; c < K; c += 256 * V) *(f32x4*)(row + c) = *(const f32x4*)(src + c);
+    } else {
+        for (int c = tid; c < K; c += 256) row[c] = src[c];
+    }
+    __syncthreads();
+    auto val = [&](int c) -> float {
+        if constexpr (sizeof(T) == 4) return (float)row[c];
+        else return qt_h16_to_f32((unsigned short)row[c], dtype);
+    };
+    const int G = K / gs;
+    for (int g = wave; g < G; g += 4) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int c = lane; c < gs; c += 64) {
+            const float w = val(g * gs + c);
+            mn = fminf(mn, w);
+            mx = fmaxf(mx, w);
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) {
+            mn = fminf(mn, 0.0f);
+            mx = fmaxf(mx, 0.0f);
+            float s, z;
+            const float eps = 1.1920928955078125e-07f;
+            if (symmetric) {
+                const float amax = fmaxf(fabsf(mn), fabsf(mx));
+                s = amax / ((qmax - qmin) / 2.0f);
+                s = fmaxf(s, eps);
+                z = 0.0f;
+            } else {
+                s = (mx - mn) / (qmax - qmin);
+                s = fmaxf(s, eps);
+                z = qmin - mn / s;
+                z = fminf(fmaxf(rintf(z), qmin), qmax);
+            }
+            scale[(size_t)r * G + g] = s;
+            zp[(size_t)r * G + g] = z;
+            if (scale_t) scale_t[(size_t)g * ld_t + r] = s;
+            if (zp_t) zp_t[(size_t)g * ld_t + r] = z;
+        }
+    }
+    float* dst = out + (size_t)r * K;
+    if (K % 4 == 0) {
+        for (int s4 = tid * 4; s4 < K; s4 += 1024) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sp = s4 + e;
+                const float x = val(perm ? perm[sp] : sp);
+                v[e] = (dead && dead[sp]) ? 0.0f : x;
+            }
+            *(f32x4*)(dst + s4) = v;
+        }
+    } else {
+        for (int sp = tid; sp < K; sp += 256) {
+            const float x = val(perm ? perm[sp] : sp);
+            dst[sp] = (dead && dead[sp]) ? 0.0f : x;
+        }
+    }
+}
+
 // packed[r][w] from Qt[K][R]; workgroup = 64 rows x 32 words, transposed through LDS so that
 // reads run along rows (contiguous in Qt) and writes along words (contiguous in packed).
 __global__ __launch_bounds__(256) void pack_int4_kernel(const int8_t* __restrict__ Qt, int R, int K,
@@ -182,6 +261,43 @@ extern "C" int qt_weight_gather_f32(const void* W, int w_dtype, int R, int K, in
                            W_f32 + (size_t)row0 * K);
         QT_LAUNCH_CHECK();
     }
+    return QT_OK;
+}
+
+extern "C" int qt_weight_gather_qparams(const void* W, int w_dtype, int R, int K, int64_t ldw, const int32_t* perm,
+                                        const uint8_t* dead, int group_size, int symmetric, int num_bits, float* W_f32,
+                                        float* scale, float* zp, float* scale_t, float* zp_t, int64_t ld_t,
+                                        qt_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    QT_CHECK_ARG(W && W_f32 && scale && zp && R > 0 && K > 0, "qt_weight_gather_qparams: bad arguments");
+    QT_CHECK_ARG(qt_dtype_ok(w_dtype), "qt_weight_gather_qparams: dtype %d unsupported", w_dtype);
+    QT_CHECK_ARG(num_bits >= 2 && num_bits <= 8, "qt_weight_gather_qparams: num_bits=%d", num_bits);
+    const int gs = group_size <= 0 ? K : group_size;
+    QT_CHECK_ARG(K % gs == 0, "qt_weight_gather_qparams: K=%d not divisible by group_size=%d", K, gs);
+    QT_CHECK_ARG((!scale_t && !zp_t) || ld_t >= R, "qt_weight_gather_qparams: ld_t=%lld < R=%d", (long long)ld_t, R);
+    const size_t esz = qt_dtype_size(w_dtype);
+    const size_t lds = qt_align_up((size_t)K * esz, 16);
+    QT_CHECK_ARG(lds <= 160 * 1024, "qt_weight_gather_qparams: a row of %d elements does not fit the LDS", K);
+    QT_CHECK_ARG(((uintptr_t)W_f32 & 15) == 0, "qt_weight_gather_qparams: W_f32 must be 16-byte aligned");
+    float qmin, qmax;
+    qt_range(num_bits, &qmin, &qmax);
+    static QtOncePerDevice attr16, attr32;
+    if (esz == 2) {
+        QT_HIP(attr16.run([&] {
+            return hipFuncSetAttribute((const void*)gather_qparams_kernel<unsigned short>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }));
+        hipLaunchKernelGGL(gather_qparams_kernel<unsigned short>, dim3(R), dim3(256), lds, stream, (const unsigned short*)W,
+                           w_dtype, R, K, ldw, perm, dead, gs, symmetric, qmin, qmax, W_f32, scale, zp, scale_t, zp_t, ld_t);
+    } else {
+        QT_HIP(attr32.run([&] {
+            return hipFuncSetAttribute((const void*)gather_qparams_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+        }));
+        hipLaunchKernelGGL(gather_qparams_kernel<float>, dim3(R), dim3(256), lds, stream, (const float*)W, w_dtype, R, K, ldw,
+                           perm, dead, gs, symmetric, qmin, qmax, W_f32, scale, zp, scale_t, zp_t, ld_t);
+    }
+    QT_LAUNCH_CHECK();
     return QT_OK;
 }
 

@@ -267,34 +267,33 @@ def gptq_quantize_batched(groups: Sequence[Tuple[Sequence[torch.Tensor], Hessian
 
     # ---- stacked fp32 working copy in sweep order, observer (a10) ------------------------------------
     Wf = torch.empty((R, K), dtype=torch.float32, device=dev)
-    scale = torch.empty((R, G), dtype=torch.float32, device=dev)
-    zp = torch.empty((R, G), dtype=torch.float32, device=dev)
     g_sweeps = []
-    for b, (ws, acc) in enumerate(groups):
-        r0 = row_begin[b]
-        for w, r in zip(ws, rows[b]):
-            if w.stride(1) != 1:
-                w = w.contiguous()
-            ops.weight_gather_f32(w, perms[b], deads[b], out=Wf[r0:r0 + r])
-            r0 += r
-        if actorder == "group":
-            # qparams on the permuted matrix; groups are runs of 128 sweep positions
-            s_, z_, _, _ = ops.group_minmax_qparams(Wf[row_begin[b]:row_end[b]], gs, qargs.symmetric, qargs.num_bits)
-            scale[row_begin[b]:row_end[b]] = s_
-            zp[row_begin[b]:row_end[b]] = z_
-            g_sweeps.append(g_orig)
-        else:
-            # qparams on the ORIGINAL matrix (before permutation / dead-column zeroing)
+    if actorder == "group":
+        # qparams on the PERMUTED matrix (groups are runs of 128 sweep positions): gather first, then one observer
+        # pass over the stacked rows
+        for b, (ws, acc) in enumerate(groups):
             r0 = row_begin[b]
             for w, r in zip(ws, rows[b]):
-                s_, z_, _, _ = ops.group_minmax_qparams(w if w.stride(1) == 1 else w.contiguous(), gs,
-                                                        qargs.symmetric, qargs.num_bits)
-                scale[r0:r0 + r] = s_
-                zp[r0:r0 + r] = z_
+                ops.weight_gather_f32(w if w.stride(1) == 1 else w.contiguous(), perms[b], deads[b], out=Wf[r0:r0 + r])
+                r0 += r
+            g_sweeps.append(g_orig)
+        scale, zp, scale_t, zp_t = ops.group_minmax_qparams(Wf, gs, qargs.symmetric, qargs.num_bits)
+    else:
+        # qparams on the ORIGINAL matrix (before permutation / dead-column zeroing) and the working copy in sweep order
+        # from ONE read of every weight; the group-major tables the sweep reads are written in place (a Linear's rows
+        # are a column range of them)
+        scale = torch.empty((R, G), dtype=torch.float32, device=dev)
+        zp = torch.empty((R, G), dtype=torch.float32, device=dev)
+        scale_t = torch.empty((G, R), dtype=torch.float32, device=dev)
+        zp_t = torch.empty((G, R), dtype=torch.float32, device=dev)
+        for b, (ws, acc) in enumerate(groups):
+            r0 = row_begin[b]
+            for w, r in zip(ws, rows[b]):
+                ops.weight_gather_qparams(w if w.stride(1) == 1 else w.contiguous(), perms[b], deads[b], gs, qargs.symmetric,
+                                          qargs.num_bits, out=Wf[r0:r0 + r], scale=scale[r0:r0 + r], zp=zp[r0:r0 + r],
+                                          scale_t=scale_t[:, r0:r0 + r], zp_t=zp_t[:, r0:r0 + r])
                 r0 += r
             g_sweeps.append(g_orig if perms[b] is None else g_orig[perms[b].long()].contiguous())
-    scale_t = scale.t().contiguous()
-    zp_t = zp.t().contiguous()
 
     # ---- the sweep (a11): all groups' rows at once, each row against its group's factor --------------
     if keeps is not None:  # stage boundaries for the parity tests

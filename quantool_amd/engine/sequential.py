@@ -290,6 +290,39 @@ def build_batches(dataset, tokenizer, num_samples: int, max_seq_length: int, shu
     return out
 
 
+def stack_batches(batches: List[Dict[str, torch.Tensor]], max_tokens: int) -> List[Dict[str, torch.Tensor]]:
+    """Consecutive calibration samples with the same keys and the same ``[1, T]``-shaped tensors, concatenated along
+    the batch dimension up to ``max_tokens`` tokens per forward (``merge_cache`` does the same to cached layer inputs;
+    the sample count is the batch dimension, so ``num_added`` stays one per sample)."""
+    if max_tokens <= 0:
+        return list(batches)
+
+    def sig(b):
+        return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in b.items())) if all(
+            torch.is_tensor(v) and v.dim() == 2 and v.shape[0] == 1 for v in b.values()) else None
+
+    out, run = [], []
+
+    def close():
+        if len(run) == 1:
+            out.append(run[0])
+        elif run:
+            out.append({k: torch.cat([r[k] for r in run], 0) for k in run[0]})
+        run.clear()
+
+    for b in batches:
+        s_b = sig(b)
+        tokens = next(iter(b.values())).shape[1] if s_b is not None else 0
+        if run and (s_b is None or s_b != sig(run[0]) or (len(run) + 1) * tokens > max_tokens):
+            close()
+        if s_b is None:
+            out.append(b)
+        else:
+            run.append(b)
+    close()
+    return out
+
+
 def _to_dev(x, dev):
     if isinstance(x, torch.Tensor):
         return x.to(dev)
@@ -403,15 +436,18 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
     ph = _Phases(dev)
     ph.start()
     h = layers[0].register_forward_pre_hook(grab, with_kwargs=True)
+    batch_tokens = int(os.environ.get("QT_CALIB_BATCH_TOKENS", "32768"))
     with torch.no_grad():
-        for b in batches:
+        # equal-shape samples share a forward already here (the embedding is per token): 512 one-sample forwards up to
+        # the first decoder layer were 0.2 s of a Llama-3-8B-sized job.  QT_CALIB_BATCH_TOKENS=0: one sample per forward.
+        for b in stack_batches(batches, batch_tokens):
             try:
                 model(**_to_dev(b, dev), use_cache=False)
             except _StopForward:
                 pass
     h.remove()
-    # equal-shape samples share a forward from here on (QT_CALIB_BATCH_TOKENS=0: one sample per forward)
-    cache = merge_cache(cache, int(os.environ.get("QT_CALIB_BATCH_TOKENS", "32768")))
+    # whatever could not be stacked before the forward (extra inputs of unequal shape) is merged after it
+    cache = merge_cache(cache, batch_tokens)
     ph.stop("first-layer inputs")
 
     prefix_of = {id(m): n for n, m in model.named_modules()}
@@ -438,8 +474,15 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             # kept alive until the grouping is done: a freed activation's address can be handed to
             # a later, unrelated tensor of the same shape, and pointer equality would then lie.
             seen: Dict[str, torch.Tensor] = {}
-            hooks = [m.register_forward_pre_hook((lambda name: lambda _m, a: seen.__setitem__(name, a[0]))(n))
-                     for n, m in linears.items()]
+            calls: Dict[str, int] = {}
+
+            def discover(name):
+                def fn(_m, a):
+                    seen[name] = a[0]
+                    calls[name] = calls.get(name, 0) + 1
+                return fn
+
+            hooks = [m.register_forward_pre_hook(discover(n)) for n, m in linears.items()]
             args, kwargs = cache[0]
             layer(*args, **kwargs)
             for hk in hooks:
@@ -472,6 +515,14 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             # per forward a [B, T, K] input counts B, and a flattened [tokens, K] input (OPT's fc1, routed expert
             # tokens) counts the samples of the forward it came from
             cur = _CALIB_CTX
+            # A calibration forward is over once every input group has seen its rows: what the layer computes behind
+            # its last hooked Linear (that Linear's own GEMM -- down_proj is a quarter of a Llama layer's flops -- and
+            # the residual add) is recomputed by the propagate pass with the quantised weights anyway.  Only when the
+            # discovery pass reached every targeted Linear exactly once (no weight shared between two call sites, no
+            # expert left out by the router); a forward in which some group does not fire simply runs to its end.
+            early_stop = (os.environ.get("QT_CALIB_EARLY_STOP", "1") != "0"
+                          and all(calls.get(n, 0) == 1 for n in linears))
+            fired = set()
 
             def add_hook(lead):
                 def fn(_m, a):
@@ -480,6 +531,9 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                         accs[lead].add(x.reshape(-1, x.shape[-2], x.shape[-1]))
                     else:
                         accs[lead].add(x.unsqueeze(0), num_samples=cur["samples"])
+                    fired.add(lead)
+                    if early_stop and len(fired) == len(leaders):
+                        raise _StopForward
                 return fn
 
             hooks = [linears[lead].register_forward_pre_hook(add_hook(lead)) for lead in leaders]
@@ -488,16 +542,23 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 h0 = args[0] if args else None
                 cur["samples"] = int(h0.shape[0]) if torch.is_tensor(h0) and h0.dim() >= 3 else 1
                 cur["tokens_per_sample"] = int(h0.shape[1]) if torch.is_tensor(h0) and h0.dim() >= 3 else None
-                layer(*args, **kwargs)
+                fired.clear()
+                try:
+                    layer(*args, **kwargs)
+                except _StopForward:
+                    pass
             for hk in hooks:
                 hk.remove()
             for a_ in accs.values():
                 a_.flush()
             ph.stop("calibration forwards + Gram")
             ph.start()
-            # one stream per input group, largest in_features first (longest chain): see streams.py;
-            # under torchrun one stream, so that every rank issues its collectives in the same order
-            pool = GroupStreams(dev) if world == 1 else None
+            # one stream per input group, largest in_features first (longest chain): see streams.py.  Also under
+            # torchrun: the collectives inside a group's chain (the all-reduce of its Gram sum, the all-gather of its
+            # rows) are issued by this one host thread in the same order on every rank whatever stream is current
+            # (torch.distributed orders them on the process group's own stream behind an event of the current one);
+            # QT_DIST_GROUP_STREAMS=0 puts everything back on one stream
+            pool = GroupStreams(dev) if (world == 1 or os.environ.get("QT_DIST_GROUP_STREAMS", "1") != "0") else None
 
             def quantize_group(lead, names):
                 ws = [linears[n].weight.data for n in names]

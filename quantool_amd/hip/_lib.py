@@ -45,6 +45,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "qt_weight_gather_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
+    "qt_weight_gather_qparams": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "qt_gptq_sweep_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "qt_gptq_sweep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -335,6 +335,41 @@ def weight_gather_f32(W: torch.Tensor, perm: Optional[torch.Tensor] = None, dead
     return out
 
 
+def weight_gather_qparams(W: torch.Tensor, perm: Optional[torch.Tensor], dead: Optional[torch.Tensor], group_size: int,
+                          symmetric: bool, num_bits: int, out: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor,
+                          scale_t: Optional[torch.Tensor] = None, zp_t: Optional[torch.Tensor] = None) -> None:
+    """``group_minmax_qparams(W)`` and ``weight_gather_f32(W, perm, dead)`` in one read of W.  ``out`` fp32 [R, K],
+    ``scale`` / ``zp`` fp32 [R, G] contiguous; ``scale_t`` / ``zp_t``: [G, R] views with unit column stride (a column
+    range of a table spanning more rows is fine: the row stride is passed on)."""
+    lib = load()
+    if W.dim() != 2 or not W.is_cuda or W.stride(1) != 1:
+        raise ValueError("W must be a 2-d device tensor with unit column stride")
+    R, K = W.shape
+    gs = K if group_size <= 0 else group_size
+    if K % gs:
+        raise ValueError(f"K={K} not divisible by group_size={gs}")
+    G = K // gs
+    for name, t, shape in (("out", out, (R, K)), ("scale", scale, (R, G)), ("zp", zp, (R, G))):
+        _req(t, torch.float32, name, 2)
+        if tuple(t.shape) != shape or not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous {shape}")
+    ld_t = 0
+    for name, t in (("scale_t", scale_t), ("zp_t", zp_t)):
+        if t is not None:
+            _req(t, torch.float32, name, 2)
+            if tuple(t.shape) != (G, R) or t.stride(1) != 1 or (ld_t and t.stride(0) != ld_t):
+                raise ValueError(f"{name} must be a [G, R] view with unit column stride (and the row stride of its twin)")
+            ld_t = t.stride(0) if G > 1 else max(R, t.stride(0))
+    for name, t, dt in (("perm", perm, torch.int32), ("dead", dead, torch.uint8)):
+        if t is not None:
+            _req(t, dt, name, 1)
+            if t.numel() != K or not t.is_contiguous():
+                raise ValueError(f"{name} must be contiguous [K]")
+    check("qt_weight_gather_qparams", lib.qt_weight_gather_qparams(
+        W.data_ptr(), _dtype_code(W), R, K, W.stride(0), _ptr(perm), _ptr(dead), group_size, int(bool(symmetric)), num_bits,
+        out.data_ptr(), scale.data_ptr(), zp.data_ptr(), _ptr(scale_t), _ptr(zp_t), ld_t, _stream()))
+
+
 # ---- a11 ----------------------------------------------------------------------------------
 def gptq_sweep(W: torch.Tensor, U: torch.Tensor, scale_t: torch.Tensor, zp_t: torch.Tensor, g_idx: torch.Tensor,
                blocksize: int = 128, num_bits: int = 4):

@@ -492,3 +492,30 @@ def test_xtx_dot_is_the_frobenius_product_with_the_gram_matrix(ops, dev, n, K, d
     ops.xtx_dot(X, H_lower_only, scale=0.5, out=acc, accumulate=True)
     torch.cuda.synchronize()
     assert abs(float(acc.item()) - 2 * float(out.item())) <= 1e-6 * abs(float(out.item())) + 1e-30
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("K,gs,sym,bits", [(512, 128, True, 4), (1152, 128, False, 4), (200, -1, True, 8), (4096, 128, True, 4)])
+def test_fused_gather_qparams_equals_the_two_passes(ops, dev, dtype, K, gs, sym, bits):
+    """``qt_weight_gather_qparams`` (one read of W) against ``qt_group_minmax_qparams`` + ``qt_weight_gather_f32``: the
+    same bits everywhere, also when the group-major tables are a column range of wider ones."""
+    g = torch.Generator(device=dev).manual_seed(K + bits)
+    R = 72
+    W = (torch.randn((R, K), generator=g, device=dev) * 0.05).to(dtype)
+    W[:, 5] = 0
+    perm = torch.randperm(K, generator=g, device=dev).to(torch.int32)
+    dead = (torch.rand(K, generator=g, device=dev) < 0.02).to(torch.uint8)
+    for pm, dd in ((perm, dead), (None, None)):
+        s0, z0, st0, zt0 = ops.group_minmax_qparams(W, gs, sym, bits)
+        w0 = ops.weight_gather_f32(W, pm, dd)
+        G = s0.shape[1]
+        out = torch.empty((R, K), dtype=torch.float32, device=dev)
+        s1, z1 = torch.empty_like(s0), torch.empty_like(z0)
+        wide_s = torch.full((G, R + 56), -1.0, device=dev)
+        wide_z = torch.full((G, R + 56), -1.0, device=dev)
+        ops.weight_gather_qparams(W, pm, dd, gs, sym, bits, out=out, scale=s1, zp=z1, scale_t=wide_s[:, 24:24 + R],
+                                  zp_t=wide_z[:, 24:24 + R])
+        torch.cuda.synchronize()
+        assert torch.equal(out, w0) and torch.equal(s1, s0) and torch.equal(z1, z0)
+        assert torch.equal(wide_s[:, 24:24 + R], st0) and torch.equal(wide_z[:, 24:24 + R], zt0)
+        assert bool((wide_s[:, :24] == -1).all()) and bool((wide_s[:, 24 + R:] == -1).all())
