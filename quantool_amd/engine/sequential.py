@@ -604,7 +604,7 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                         results[n] = r
 
             by_size = sorted(leaders.items(), key=lambda kv: (-linears[kv[0]].in_features, kv[0]))
-            if pool is not None and batch_chains_enabled():
+            if world == 1 and pool is not None and batch_chains_enabled():     # (under ranks every group is row-split instead)
                 live = [lead for lead, _ in by_size if accs[lead].n > 0]
                 for lead, names in by_size:
                     if accs[lead].n == 0:
