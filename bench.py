@@ -125,8 +125,6 @@ BATCH_CHAINS = os.environ.get("QT_BATCH_CHAINS", "1") != "0"
 # QT_BENCH_SHAPE_SCALE=d: every width of the model's layer divided by d (multiples of 128) -- control-flow rehearsals of
 # configs[3] / configs[4] with N ranks on one GPU (tests/test_gpu_bench_rehearsal.py); the line is labelled, not a result.
 SHAPE_SCALE = int(os.environ.get("QT_BENCH_SHAPE_SCALE", "1") or 1)
-# QT_BENCH_GRAM_CUS=n: the Gram stream may occupy only n of the 256 CUs (hipExtStreamCreateWithCUMask); 0 = all
-GRAM_CUS = int(os.environ.get("QT_BENCH_GRAM_CUS", "0") or 0)
 _DIAG_G = {}
 
 
@@ -159,12 +157,7 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
     if xmode in ("shared", "prio", "lane"):
         key = (dev.index, "xtx") if xmode == "shared" else (dev.index, "xtx", lane)
         if key not in _STREAMS:
-            if GRAM_CUS > 0:      # the Gram stream restricted to a share of the CUs (chain kernels find the rest free)
-                from quantool_amd.hip import ops as _ops
-
-                _STREAMS[key] = _ops.cu_masked_stream(dev, GRAM_CUS)
-            else:
-                _STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1 if xmode == "prio" else 0)
+            _STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1 if xmode == "prio" else 0)
         sx = _STREAMS[key]
         sx.wait_stream(main)
     pending = []

@@ -269,12 +269,6 @@ int qt_gemm3_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, fl
 /* Host-only self-check of the bf16x3 block-row planner (runs without a GPU): 0 if every k chunk of every tile is
  * covered exactly once and the slab / reduction tables are consistent, else a negative code. */
 int qt_gemm3_plan_check(int Tm, int Tn, int c_end, int tri, int* n_items_out, int* n_slabs_out, int* longest_out);
-/* ---- scheduling aid of the host drivers (not part of the reference surface) ---------------------
- * A stream whose kernels may only occupy the CUs whose bit is set in mask[0..n_words) (bit i of word w = CU 32 w + i
- * in the runtime's numbering).  Destroy with qt_stream_destroy. */
-int qt_stream_create_cu_mask(const uint32_t* mask, int n_words, qt_stream_t* stream_out);
-int qt_stream_destroy(qt_stream_t stream);
-
 /* ---- measurement aid (bench.py roofline leg; not part of the reference surface) -------------
  * When enabled, HIP events are recorded on the launch stream immediately around the named
  * kernel; qt_profile_read synchronises them, returns the summed device time and the launch

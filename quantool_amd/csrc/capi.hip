@@ -76,20 +76,3 @@ extern "C" int qt_profile_read(int kernel_id, double* total_ms, int64_t* launche
     *launches = n;
     return QT_OK;
 }
-
-// ---- streams restricted to a subset of the CUs (scheduling aid of the host drivers) --------------
-// A stream whose kernels may only occupy the CUs whose bit is set (hipExtStreamCreateWithCUMask).  The Gram kernel fills
-// every CU it is given for the whole of a ~30 ms launch; run on a stream that leaves a few CUs out, the latency-bound
-// chain kernels of the other streams find a free CU at once instead of queueing behind it.
-extern "C" int qt_stream_create_cu_mask(const uint32_t* mask, int n_words, qt_stream_t* stream_out) {
-    QT_CHECK_ARG(mask && n_words > 0 && stream_out, "qt_stream_create_cu_mask: bad arguments");
-    hipStream_t st = nullptr;
-    QT_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask));
-    *stream_out = (qt_stream_t)st;
-    return QT_OK;
-}
-
-extern "C" int qt_stream_destroy(qt_stream_t stream) {
-    if (stream) QT_HIP(hipStreamDestroy((hipStream_t)stream));
-    return QT_OK;
-}

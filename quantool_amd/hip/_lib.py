@@ -86,8 +86,6 @@ SIGNATURES = {
     "qt_sgemm_tn_f32_workspace_bytes": (c_size_t, [c_int, c_int]),
     "qt_sgemm_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                 c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "qt_stream_create_cu_mask": (c_int, [c_void_p, c_int, c_void_p]),
-    "qt_stream_destroy": (c_int, [c_void_p]),
     "qt_profile_enable": (c_int, [c_int]),
     "qt_profile_read": (c_int, [c_int, c_void_p, c_void_p]),
     "qt_dequantize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

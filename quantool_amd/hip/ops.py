@@ -100,21 +100,6 @@ def _req(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None):
         raise ValueError(f"{name} must be {ndim}-d, got shape {tuple(t.shape)}")
 
 
-def cu_masked_stream(device, n_cus: int, total_cus: int = 256) -> "torch.cuda.Stream":
-    """A torch stream whose kernels may occupy only the first ``n_cus`` CUs of the runtime's numbering (the driver deals
-    mask bits round-robin over the XCDs and shader engines, so a prefix is an even share of each)."""
-    import ctypes
-
-    lib = load()
-    n_cus = max(1, min(int(n_cus), total_cus))
-    words = (total_cus + 31) // 32
-    mask = (ctypes.c_uint32 * words)(*[(0xFFFFFFFF if n_cus >= 32 * (w + 1) else ((1 << max(0, n_cus - 32 * w)) - 1)) for w in range(words)])
-    out = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        check("qt_stream_create_cu_mask", lib.qt_stream_create_cu_mask(ctypes.cast(mask, ctypes.c_void_p), words, ctypes.byref(out)))
-    return torch.cuda.ExternalStream(out.value, device=device)
-
-
 def workspace(nbytes: int, device, tag: str = "default") -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag); reused across calls on the same stream."""
     # one scratch buffer per (device, stream, tag): groups running on different streams never share
