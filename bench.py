@@ -219,8 +219,18 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
     # factorisation, one stacked sweep (gptq_quantize_batched) -- on the stream of the first of them, behind the Gram
     # passes of all of them.  QT_BATCH_CHAINS=0: a chain per group on its own stream (rounds 1-3).
     if pending:
-        for idx in batchable([([w[n] for n, _ in l], a) for _, _, l, w, a, _, _ in pending]):
-            run_chains([pending[i] for i in idx])
+        for bi, idx in enumerate(batchable([([w[n] for n, _ in l], a) for _, _, l, w, a, _, _ in pending])):
+            members = [pending[i] for i in idx]
+            if overlap:
+                # a batch (also a batch of one) runs on the stream slot of its index, not of its first member: a Mixtral
+                # layer's two batches -- ten groups of K = 4096, eight of K = 14336 -- would otherwise both land on
+                # slot 0 and run one after the other
+                if (dev.index, lane, bi % 4) not in _STREAMS:
+                    _STREAMS[(dev.index, lane, bi % 4)] = torch.cuda.Stream(device=dev)
+                st_b = _STREAMS[(dev.index, lane, bi % 4)]
+                st_b.wait_stream(main)
+                members = [m[:5] + (st_b,) + m[6:] for m in members]
+            run_chains(members)
     return outs
 
 
@@ -717,6 +727,9 @@ def main():
             "per_rank_compute_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
             "gather_ms": round((elapsed - max(per_rank)) * 1e3, 3) if world > 1 else 0.0,
             "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
+            "layers_in_flight": args.lanes,
+            "peak_hbm_GiB": {"allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                             "reserved": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)},
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, ranks share one GPU)" if REHEARSE else ""),
             "config": {

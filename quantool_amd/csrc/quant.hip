@@ -183,6 +183,46 @@ __global__ __launch_bounds__(256) void pack_int4_kernel(const int8_t* __restrict
     }
 }
 
+// The same with FOUR rows per lane on the read side (R % 4 == 0, Qt 4-byte aligned): a lane's load is one 32-bit word =
+// the levels of rows 4 rq .. 4 rq + 3 at one sweep position, so a wave's load instruction moves 256 contiguous bytes
+// instead of 64.  Workgroup = 256 rows x 32 words.
+__global__ __launch_bounds__(256) void pack_int4_rows4_kernel(const int8_t* __restrict__ Qt, int R, int K,
+                                                              const int32_t* __restrict__ col_src,
+                                                              int32_t* __restrict__ packed) {
+    __shared__ uint32_t tile[256][33];
+    const int Kw = (K + 7) / 8;
+    const int r0 = blockIdx.y * 256, w0 = blockIdx.x * 32;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * 32; e += 256) {
+        const int rq = e & 63, wl = e >> 6;
+        const int r = r0 + 4 * rq, w = w0 + wl;
+        uint32_t acc[4] = {0, 0, 0, 0};
+        if (r < R && w < Kw) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = w * 8 + j;
+                if (c < K) {
+                    const int sc = col_src ? col_src[c] : c;
+                    const uint32_t q4 = *(const uint32_t*)(Qt + (size_t)sc * R + r);   // rows r .. r + 3
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t u = (uint32_t)((int)(int8_t)(q4 >> (8 * i)) + 8) & 0xFu;
+                        acc[i] |= u << (4 * j);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[4 * rq + i][wl] = acc[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < 256 * 32; e += 256) {
+        const int wl = e & 31, rl = e >> 5;
+        const int r = r0 + rl, w = w0 + wl;
+        if (r < R && w < Kw) packed[(size_t)r * Kw + w] = (int32_t)tile[rl][wl];
+    }
+}
+
 // out[r][c] = (q - zp[r][g(c)]) * scale[r][g(c)]; 64x64 tiles transposed through LDS
 __global__ __launch_bounds__(256) void dequant_kernel(const int8_t* __restrict__ Qt, int R, int K,
                                                       const int32_t* __restrict__ col_src,
@@ -306,8 +346,12 @@ extern "C" int qt_pack_int4(const int8_t* Qt, int R, int K, const int32_t* col_s
     hipStream_t stream = (hipStream_t)stream_;
     QT_CHECK_ARG(Qt && packed && R > 0 && K > 0, "qt_pack_int4: bad arguments");
     const int Kw = (K + 7) / 8;
-    hipLaunchKernelGGL(pack_int4_kernel, dim3((Kw + 31) / 32, (R + 63) / 64), dim3(256), 0, stream, Qt, R, K, col_src,
-                       packed);
+    if (R % 4 == 0 && (((uintptr_t)Qt) & 3) == 0 && (R + 255) / 256 <= 65535)
+        hipLaunchKernelGGL(pack_int4_rows4_kernel, dim3((Kw + 31) / 32, (R + 255) / 256), dim3(256), 0, stream, Qt, R, K,
+                           col_src, packed);
+    else
+        hipLaunchKernelGGL(pack_int4_kernel, dim3((Kw + 31) / 32, (R + 63) / 64), dim3(256), 0, stream, Qt, R, K, col_src,
+                           packed);
     QT_LAUNCH_CHECK();
     return QT_OK;
 }

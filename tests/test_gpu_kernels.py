@@ -440,7 +440,7 @@ def test_sweep_bit_exact_given_same_U(ops, oracle, dev, R, K, gs, sym):
 
 
 # ------------------------------------------------------------------------------------- a14
-@pytest.mark.parametrize("R,K,perm", [(16, 64, False), (70, 264, True), (64, 4096, True), (5, 20, False)])
+@pytest.mark.parametrize("R,K,perm", [(16, 64, False), (70, 264, True), (64, 4096, True), (5, 20, False), (300, 520, True), (516, 36, False)])
 def test_pack_and_dequant_exact(ops, oracle, dev, R, K, perm):
     rng = np.random.default_rng(R * K)
     Q = rng.integers(-8, 8, size=(R, K)).astype(np.int8)  # levels in ORIGINAL column order
