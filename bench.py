@@ -286,8 +286,14 @@ def stage_split(shape, weights, acts, n_samples, smooth=None):
         (perm, inv), row["order"] = timed(lambda: ops.argsort_desc(diag))
         (A, dead, _), row["prepare"] = timed(lambda: ops.hessian_prepare(G, n_samples, 0.01, perm))
         (U, info), row["factor"] = timed(lambda: ops.cholesky_inverse_upper(A))
-        Wf, row["gather"] = timed(lambda: ops.weight_gather_f32(W, perm, dead))
-        (sc, zp, sct, zpt), row["qparams"] = timed(lambda: ops.group_minmax_qparams(W, 128, True, 4))
+        # observer + working copy in ONE read of W (round 4: qt_weight_gather_qparams; rounds 1-3 timed two passes,
+        # "gather" and "qparams")
+        R_, G_ = int(W.shape[0]), K // 128
+        Wf = torch.empty((R_, K), dtype=torch.float32, device=X.device)
+        sc, zp = torch.empty((R_, G_), device=X.device), torch.empty((R_, G_), device=X.device)
+        sct, zpt = torch.empty((G_, R_), device=X.device), torch.empty((G_, R_), device=X.device)
+        _, row["gather_qparams"] = timed(lambda: ops.weight_gather_qparams(W, perm, dead, 128, True, 4, out=Wf, scale=sc, zp=zp,
+                                                                          scale_t=sct, zp_t=zpt))
         g_sweep = (torch.arange(K, device=X.device, dtype=torch.int32) // 128)[perm.long()].contiguous()
         (Qt, loss), row["sweep"] = timed(lambda: ops.gptq_sweep(Wf, U, sct, zpt, g_sweep, 128, 4))
         _, row["pack"] = timed(lambda: ops.pack_int4(Qt, inv))
@@ -296,7 +302,7 @@ def stage_split(shape, weights, acts, n_samples, smooth=None):
         # ALGORITHMIC work of the stages: flops for the MFMA-bound ones, bytes for the single passes
         N, R = int(X.shape[0]), int(W.shape[0])
         for k, w in (("gram", N * K * (K + 1)), ("factor", 2 * K ** 3 // 3), ("sweep", R * K * K),
-                     ("prepare", 4 * K * K), ("gather", 6 * R * K), ("qparams", 2 * R * K), ("pack", 3 * R * K // 2)):
+                     ("prepare", 4 * K * K), ("gather_qparams", 6 * R * K), ("pack", 3 * R * K // 2)):
             work[k] = work.get(k, 0) + w
         del G, A, U, Wf, Qt, W
     rates = {}
@@ -673,7 +679,7 @@ def main():
         "note": ("achieved/frac: live in the timed region, flop-weighted over the step's Gram launches (one per "
                  "distinct input: " + ", ".join(f"{sum(1 for _, k, _ in shape.groups if k == K)}x K={K}"
                                                 for K in sorted({k for _, k, _ in shape.groups})) + "); the groups of "
-                 "a layer and two layers run concurrently on separate streams, so a live launch shares the CUs with "
+                 f"a layer and {args.lanes} layers run concurrently on separate streams, so a live launch shares the CUs with "
                  "other kernels. *_isolated: one launch per distinct K (2 repetitions) alone on the GPU right after "
                  "the timed region. traffic: from the committed PMC profile of the Llama-3-8B workload (bench.py "
                  "cannot run the profiler). north_star's HBM figure is hbm_GBps_algorithmic; X^T X is MFMA-bound "
