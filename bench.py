@@ -602,6 +602,7 @@ def main():
     lib.qt_profile_enable(1)
     kept = []
     barrier()
+    mem0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kept.append(step(_))
@@ -609,6 +610,10 @@ def main():
     join_streams(dev)
     torch.cuda.synchronize()
     t_compute = time.perf_counter() - t0          # this rank's own steps, before the collective
+    mem1 = torch.cuda.memory_stats(dev)
+    # hipMalloc / hipFree calls of the caching allocator INSIDE the timed region (each one is a host stall, a hipFree a
+    # device synchronisation): 0 when the warm-up steps have sized every pool
+    allocator = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
     if dist is not None:
         # final gather of the packed state to rank 0 (the job's only collective)
         from quantool_amd.engine.sharding import gather_state_dict
@@ -734,6 +739,7 @@ def main():
             "gather_ms": round((elapsed - max(per_rank)) * 1e3, 3) if world > 1 else 0.0,
             "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
             "layers_in_flight": args.lanes,
+            "allocator_calls_in_timed_region": allocator,
             "peak_hbm_GiB": {"allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                              "reserved": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)},
             "higher_is_better": True, "scaling": "weak",
