@@ -30,7 +30,8 @@ def lib_path():
 def test_header_declares_the_expected_surface():
     names = _declared()
     for must in ("qt_xtx_accumulate", "qt_hessian_prepare", "qt_cholesky_inverse_upper", "qt_group_minmax_qparams",
-                 "qt_gptq_sweep", "qt_pack_int4", "qt_last_error"):
+                 "qt_gptq_sweep", "qt_pack_int4", "qt_last_error", "qt_cholesky_inverse_upper_batched",
+                 "qt_gptq_sweep_grouped", "qt_weight_gather_qparams"):
         assert must in names
 
 
