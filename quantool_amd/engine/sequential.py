@@ -459,7 +459,8 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 from .awq_module import awq_layer
 
                 results.update(awq_layer(layer, lname, cache, aw, dev))
-                cache = _advance(layer, cache)
+                if li + 1 < len(layers):
+                    cache = _advance(layer, cache)
                 continue
             linears = {f"{lname}.{n}" if n else lname: m for n, m in layer.named_modules()
                        if isinstance(m, nn.Linear) and gp.wants(f"{lname}.{n}", m)}
@@ -626,7 +627,8 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             accs.clear()
             ph.stop("factorise + sweep + pack")
             ph.start()
-            cache = _advance(layer, cache)
+            if li + 1 < len(layers):       # nobody reads the last layer's outputs: no propagate pass behind it
+                cache = _advance(layer, cache)
             ph.stop("propagate")
             logger.info(f"quantized {lname}: {len(linears)} Linears in {len(leaders)} input groups")
     ph.report()

@@ -44,7 +44,7 @@ def _side(oracle, name):
     return _SIDES[name]
 
 
-def gpu_side(dev, wb, xb, actorder):
+def gpu_side(dev, wb, xb, actorder, symmetric=True):
     from quantool_amd.engine.gptq_linear import HessianAccumulator, gptq_quantize_shared
     from quantool_amd.engine.schemes import QuantArgs
 
@@ -54,7 +54,7 @@ def gpu_side(dev, wb, xb, actorder):
         acc.add(bits_to_bf16_tensor(xb[s], dev))
     keep = {}
     res = gptq_quantize_shared([bits_to_bf16_tensor(wb, dev)], acc,
-                               QuantArgs(num_bits=4, symmetric=True, group_size=128, actorder=actorder), keep=keep)[0]
+                               QuantArgs(num_bits=4, symmetric=symmetric, group_size=128, actorder=actorder), keep=keep)[0]
     torch.cuda.synchronize()
     assert acc.n == S and int(res.info.item()) == 0
     return res, keep, acc
@@ -102,3 +102,27 @@ def test_gpu_vs_oracle_forming_its_own_hessian(dev, oracle, name, actorder):
     print(f"[own-H] {name} in the GPU's sweep order on both sides: GPU vs oracle = {rate2:.3e} ({mism2}, {rows2} rows) | "
           f"H-order yardstick {y2['h_order']:.3e}")
     assert rate2 <= max(3 * max(y2["h_order"], y["factor"]), FLOOR), (rate2, y2["h_order"], y["factor"])
+
+
+@pytest.mark.parametrize("actorder,symmetric", [("group", True), ("static", False), ("group", False)])
+def test_small_case_other_schemes_with_nothing_shared(dev, oracle, actorder, symmetric):
+    """The same comparison for the schemes that save more than packed words and scales: ``actorder="group"`` keeps
+    ``weight_g_idx`` (a function of the sweep order) and takes its scales from the PERMUTED matrix, the asymmetric preset
+    keeps zero points.  At 128 x 512 the GPU's and the oracle's Hessians order the channels identically, and then every
+    saved tensor is equal to the bit."""
+    side, wb, xb = _side(oracle, "128x512")
+    res, keep, acc = gpu_side(dev, wb, xb, actorder, symmetric)
+    o = oracle.quantize_weight(side.Wf, side.H_own, actorder=actorder, symmetric=symmetric, inverse="lapack")
+    assert np.array_equal(keep["perm"].cpu().numpy().astype(np.int64), np.asarray(o["perm"], np.int64))
+    np.testing.assert_array_equal(res.scale_f32.cpu().numpy(), o["scale"])
+    np.testing.assert_array_equal(res.zp_f32.cpu().numpy(), o["zp"])
+    if actorder == "group":
+        np.testing.assert_array_equal(res.weight_g_idx.cpu().numpy(), o["g_idx"])
+    else:
+        assert res.weight_g_idx is None and o["g_idx"] is None
+    if not symmetric:
+        np.testing.assert_array_equal(res.weight_zero_point.cpu().numpy(), o["zp"].astype(np.int8))
+    rate, mism, rows = oc.nibble_rate(oracle, res.weight_packed.cpu().numpy(), o["q"])
+    print(f"\n[own-H] 128x512 actorder={actorder} symmetric={symmetric}: GPU vs oracle(own H, LAPACK) = {rate:.3e} ({mism} levels, {rows} rows)")
+    assert rate <= FLOOR
+
