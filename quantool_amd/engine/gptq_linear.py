@@ -289,9 +289,16 @@ def gptq_quantize_batched(groups: Sequence[Tuple[Sequence[torch.Tensor], Hessian
         for b, (ws, acc) in enumerate(groups):
             r0 = row_begin[b]
             for w, r in zip(ws, rows[b]):
-                ops.weight_gather_qparams(w if w.stride(1) == 1 else w.contiguous(), perms[b], deads[b], gs, qargs.symmetric,
-                                          qargs.num_bits, out=Wf[r0:r0 + r], scale=scale[r0:r0 + r], zp=zp[r0:r0 + r],
-                                          scale_t=scale_t[:, r0:r0 + r], zp_t=zp_t[:, r0:r0 + r])
+                w = w if w.stride(1) == 1 else w.contiguous()
+                if K * w.element_size() <= 160 * 1024:          # a row fits the LDS: one pass
+                    ops.weight_gather_qparams(w, perms[b], deads[b], gs, qargs.symmetric, qargs.num_bits, out=Wf[r0:r0 + r],
+                                              scale=scale[r0:r0 + r], zp=zp[r0:r0 + r], scale_t=scale_t[:, r0:r0 + r],
+                                              zp_t=zp_t[:, r0:r0 + r])
+                else:                                           # (in_features beyond 81 920: the two passes of rounds 1-3)
+                    ops.weight_gather_f32(w, perms[b], deads[b], out=Wf[r0:r0 + r])
+                    s_, z_, st_, zt_ = ops.group_minmax_qparams(w, gs, qargs.symmetric, qargs.num_bits)
+                    scale[r0:r0 + r], zp[r0:r0 + r] = s_, z_
+                    scale_t[:, r0:r0 + r], zp_t[:, r0:r0 + r] = st_, zt_
                 r0 += r
             g_sweeps.append(g_orig if perms[b] is None else g_orig[perms[b].long()].contiguous())
 
