@@ -14,11 +14,11 @@ equality; here nothing is shared, so the comparison is a RATE, read next to two 
 
 Bars
   * scales (and the absence of zero points / g_idx for the symmetric static scheme) bit-equal: they depend on W alone;
-  * actorder = None: rate(GPU vs oracle) <= 3 x max(yardstick i, yardstick ii), floor 3e-5;
+  * actorder = None: rate(GPU vs oracle) <= RATIO x max(yardstick i, yardstick ii), floor 3e-5 (measured: <= 2.5 x);
   * actorder = "static" (upstream's default): the sweep order is argsort(diag H), which flips for channels whose
     diagonals agree to the last bits -- between the GPU's and the oracle's Hessian exactly as between the oracle's two.
-    The literal rate is printed and bounded by 3 x the literal yardsticks when the GPU picked the oracle's order, else
-    by 10 x; and with the order taken out (the oracle swept in the GPU's order, yardsticks likewise) the 3 x bound holds.
+    The literal rate is printed and bounded by RATIO x the literal yardsticks when the GPU picked the oracle's order, else
+    by 10 x; and with the order taken out (the oracle swept in the GPU's order, yardsticks likewise) the RATIO bound holds.
 
 Host cost: the K = 14336 case forms one per-sample fp32 and one fp64 Hessian and factorises four times (about two to
 three minutes on the GPU box's 16 cores).
@@ -33,6 +33,11 @@ from .util import bits_to_bf16_tensor
 pytestmark = pytest.mark.gpu
 
 FLOOR = 3e-5          # a handful of levels at the small sizes
+# Asserted ratio to the yardsticks.  Measured (profiles/r04_own_hessian_parity.txt): <= 2.5 everywhere.  The CPU side --
+# both the oracle's Hessian and the yardsticks -- depends on the BLAS build and thread count of the box that runs the
+# test (that dependence is the very thing yardstick (i) measures), so the assertion leaves room above the 3x DESIGN.md
+# quotes instead of failing on another host.
+RATIO = 4.0
 _SIDES = {}
 
 
@@ -92,7 +97,7 @@ def test_gpu_vs_oracle_forming_its_own_hessian(dev, oracle, name, actorder):
           f"|dH|/sqrt(HiiHjj): GPU {h_gpu:.1e}, oracle {h_own:.1e} | sweep-order flips: GPU {flips_gpu}, yardstick {y['perm_flips']}")
     assert y["scales_equal"]
     if flips_gpu == 0:
-        assert rate <= max(3 * yard, FLOOR), (rate, y)
+        assert rate <= max(RATIO * yard, FLOOR), (rate, y)
         return
     # the argsort of near-equal diagonals came out differently: literal rate bounded loosely, then the order taken out
     assert rate <= max(10 * yard, 0.2 if y["perm_flips"] == 0 else 0.0, FLOOR), (rate, y)
@@ -101,7 +106,7 @@ def test_gpu_vs_oracle_forming_its_own_hessian(dev, oracle, name, actorder):
     rate2, mism2, rows2 = oc.nibble_rate(oracle, packed, y2["o"]["q"])
     print(f"[own-H] {name} in the GPU's sweep order on both sides: GPU vs oracle = {rate2:.3e} ({mism2}, {rows2} rows) | "
           f"H-order yardstick {y2['h_order']:.3e}")
-    assert rate2 <= max(3 * max(y2["h_order"], y["factor"]), FLOOR), (rate2, y2["h_order"], y["factor"])
+    assert rate2 <= max(RATIO * max(y2["h_order"], y["factor"]), FLOOR), (rate2, y2["h_order"], y["factor"])
 
 
 @pytest.mark.parametrize("actorder,symmetric", [("group", True), ("static", False), ("group", False)])
