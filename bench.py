@@ -132,10 +132,11 @@ def quantize_layer(shape, weights, acts, qargs, n_samples, overlap=True, lane=0,
     """One step: the hot path over one decoder layer.  Returns the packed outputs.
 
     The layer's Linear groups are independent, so each group's chain (factorise, sweep, pack) runs on
-    its own HIP stream: the latency-bound chains of one group overlap the MFMA-bound work of another.
-    The Gram passes share one further stream, smallest in_features first (below).  `lane` selects one
-    of two stream sets so that two consecutive layers (independent units in this per-Linear mode,
-    exactly as across GPUs) can be in flight at once."""
+    its own HIP stream -- since round 4 one chain per SET of equal-width groups (one batched factorisation, one
+    stacked sweep: gptq_quantize_batched) -- so the latency-bound chain of one set overlaps the MFMA-bound work of
+    another.  The Gram passes share one further stream, smallest in_features first (below).  `lane` selects one of
+    `--lanes` stream sets so that consecutive layers (independent units in this per-Linear mode, exactly as across
+    GPUs) can be in flight at once."""
     from quantool_amd.engine.gptq_linear import HessianAccumulator, batchable, gptq_quantize_batched
 
     dev = next(iter(acts.values())).device

@@ -10,6 +10,10 @@ only take turns on the CUs.  They go on ONE extra stream, smallest in_features f
 chains start within milliseconds, the long pass runs last at its stand-alone rate), and each group's
 chain waits for its own Gram sum only (round 3: same throughput, the Gram launches at 0.50 instead of
 0.34 of the MFMA peak while the chains of the other groups run beside them).
+
+Round 4: the groups of one in_features share ONE chain (``gptq_quantize_batched``: a batched factorisation, a stacked
+sweep) on one stream behind the Gram sums of all of them -- ``run(after=[events])`` -- so a Llama layer runs two chain
+streams instead of four.
 """
 from __future__ import annotations
 
