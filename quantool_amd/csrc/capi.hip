@@ -20,7 +20,7 @@ int qt_chain_prio() {
     const int v = e ? atoi(e) : 3;   // measured in the bench: 0: 92.8-93.4 ms/step, 3: 92.5
     return v < 0 ? 0 : (v > 3 ? 3 : v);
 }
-extern "C" int qt_version(void) { return 300; }  // round * 100: bumped whenever a signature in include/quantool_amd.h changes
+extern "C" int qt_version(void) { return 400; }  // round * 100: bumped whenever a signature in include/quantool_amd.h changes
 
 // ---- optional per-kernel timing with HIP events (bench.py's roofline leg) ---------------------
 // Events are recorded on the launch stream immediately around the kernel, so the elapsed time is
