@@ -57,9 +57,11 @@ static int chol_block_env(const char* name) {
 // then LEFT-looking at the outer level (block row J gathers  A[J, J:] -= R[:J0, J]^T R[:J0, J:]  in one
 // long-k product: each element of A is read and written once, where the right-looking k = 256 update of
 // the whole trailing matrix is bound by that read-modify-write), and the inverse's T_I product is the same
-// shape.  QT_CHOL_G3=0 disables; QT_CHOL_G3_MIN_CHUNKS = 128-row k-chunks a product needs (default 256 =
-// one per CU; K = 14336 / 8192 / 4096: 24.2 / 9.5 / 3.6 ms at 64...256, 24.6 at 640, 24.9 at 768; off: 34.0 /
-// 10.7 / 3.6).  Item tables for every step are built once per (K, block sizes) in pinned host memory and
+// shape.  QT_CHOL_G3=0 disables; QT_CHOL_G3_MIN_CHUNKS = 128-row k-chunks a product needs (256 =
+// one per CU in rounds 2-3; K = 14336 / 8192 / 4096: 24.2 / 9.5 / 3.6 ms at 64...256, 24.6 at 640, 24.9 at 768; off: 34.0 /
+// 10.7 / 3.6.  Round 4: 64 -- with the short f32 products split less (sgemm_tn.hip) and the chains batched, more of
+// the K = 4096 steps pay on the bf16 MFMA: single chain 3.82 -> 3.70 ms, three batched 5.55 -> 5.23, ten batched
+// 10.9 -> 10.4; K = 8192 / 14336 unchanged).  Item tables for every step are built once per (K, block sizes) in pinned host memory and
 // uploaded with one async copy per call.
 struct G3Step {
     int n_items = 0, n_red = 0;
@@ -77,7 +79,7 @@ static int chol_g3_min_chunks() {   // read per call: tests switch the path on f
     const char* on = getenv("QT_CHOL_G3");
     if (on && atoi(on) == 0) return 0;
     const char* e = getenv("QT_CHOL_G3_MIN_CHUNKS");
-    const int x = e ? atoi(e) : 256;
+    const int x = e ? atoi(e) : 64;
     return x < 1 ? 1 : x;
 }
 

@@ -580,12 +580,15 @@ int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
     // Latency-bound shape (fewer 128x128 tiles than CUs, long k): keep the MFMA-dense 128x128
     // tile and split k over workgroups to fill the chip; slabs are reduced in ascending order.
     if (a.split_ws && t128 < 384 && a.kdim >= 512) {
-        // Aim at ~8 workgroups per CU (the SET kernel fits 4 per CU at a time): measured on the
-        // Cholesky chain, K = 14336: 44.2 / 39.5 / 37.3 / 37.9 ms at 512 / 1024 / 2048 / 3072 target
-        // workgroups -- the extra slab traffic costs less than the exposed barrier / load stalls.
+        // Target workgroups per product.  Rounds 1-3: 2048 (~8 per CU), tuned on the f32 Cholesky chain at K = 14336
+        // (44.2 / 39.5 / 37.3 / 37.9 ms at 512 / 1024 / 2048 / 3072), where these products carried the K^3.  Since the
+        // bf16x3 block-row products took that over, only SHORT products come here, and since round 4 they usually come
+        // as a batch that fills the chip by itself: one round of the CUs is the better target (K = 4096: single chain
+        // 3.92 -> 3.84 ms, three batched 5.94 -> 5.62, ten batched 12.7 -> 11.1; K = 8192 / 14336 unchanged) -- a
+        // quarter of the slab traffic.  (The split is part of the bits: one value for single and batched calls.)
         static const int target_wgs = [] {
             const char* e = getenv("QT_SGEMM_SPLIT_TARGET");
-            const int v = e ? atoi(e) : 2048;
+            const int v = e ? atoi(e) : 256;
             return v < 256 ? 256 : v;
         }();
         static const int min_chunk = [] {
@@ -595,6 +598,7 @@ int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
         }();
         int splits = (int)(target_wgs / t128);
         if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
         int chunk = (a.kdim + splits - 1) / splits;
         chunk = (chunk + 63) / 64 * 64;  // whole BK steps
         if (chunk < min_chunk) chunk = min_chunk;
@@ -623,7 +627,11 @@ int qt_sgemm_tn(const SgemmArgs& a_, hipStream_t stream) {
     const char* ring_env = getenv("QT_SGEMM_RING");
     const int use_ring = (ring_env && atoi(ring_env) == 0) ? 0 : 1;
     const char* ring_min_env = getenv("QT_SGEMM_RING_MIN_TILES");
-    const int ring_min_tiles = ring_min_env ? atoi(ring_min_env) : 384;
+    // from how many 128x128 tiles on: 384 in round 3 (1.5 rounds of the CUs); round 4, with the chains batched and three
+    // layers in flight: 32 -- the persistent ring workgroups also win on the near updates and the short folds (bench
+    // 75.9-76.4 -> 74.8 ms/step over 384 / 192 / 128 / 64 / 32: 75.9 / 75.5 / 75.4 / 75.0 / 74.8; K = 14336 sweep
+    // 12.7 -> 11.9 ms alone).  Bit-identical to the register-staged kernel either way.
+    const int ring_min_tiles = ring_min_env ? atoi(ring_min_env) : 32;
     if (use_ring && a.mode == SG_MODE_SUB && a.k_mode == SG_K_FULL && a.k_chunk == 0 && a.kdim >= 4 * RBK &&
         a.kdim % (2 * RBK) == 0 && (a.chain_len == 0 || (a.chain_len % (2 * RBK) == 0 && a.kdim % a.chain_len == 0)) &&
         a.kdim % RBK == 0 && (a.chain_len == 0 || a.chain_len % RBK == 0) && a.M % RBM == 0 && a.N % RBN == 0 &&
