@@ -418,6 +418,32 @@ void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items,
     // longest items first (they all start in the first round; the order only matters beyond 256 items)
     std::stable_sort(items.begin(), items.end(),
                      [](const G3Item& x, const G3Item& y) { return (x.c_hi - x.c_lo) > (y.c_hi - y.c_lo); });
+    // Deal the items to the XCDs (workgroup i of a launch runs on XCD i % 8; the <= 256 items of a product start
+    // together and stream their k ranges in step): items that read the SAME k rows -- the same piece of different
+    // tiles -- go to one XCD, where the A panel of a tile row is then fetched once for all its tile columns and a B
+    // panel once for both tile rows.  The slab of an item and the reduction order do not change: same bits.
+    // QT_G3_DEAL=0: the order above (rounds 2-3).
+    static const bool deal = [] { const char* e = getenv("QT_G3_DEAL"); return !(e && atoi(e) == 0); }();
+    if (deal && items.size() > 8) {
+        std::vector<int> starts;
+        for (const G3Item& it : items) starts.push_back(it.c_lo);
+        std::sort(starts.begin(), starts.end());
+        starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+        const int P = (int)starts.size();                       // distinct k-range starts
+        const int g = P >= 8 ? 1 : 8 / P;                       // XCDs per k range when there are fewer ranges than XCDs
+        std::vector<std::vector<G3Item>> cls(8);
+        for (const G3Item& it : items) {
+            const int rank = (int)(std::lower_bound(starts.begin(), starts.end(), it.c_lo) - starts.begin());
+            const int tj = it.tile & 0xFFFF;
+            cls[(rank * g + (g > 1 ? tj % g : 0)) % 8].push_back(it);
+        }
+        std::vector<G3Item> dealt;
+        dealt.reserve(items.size());
+        for (size_t q = 0; dealt.size() < items.size(); ++q)
+            for (int x = 0; x < 8; ++x)
+                if (q < cls[x].size()) dealt.push_back(cls[x][q]);
+        items.swap(dealt);
+    }
 }
 
 // ---- C-ABI face (tests and micro-benchmarks; the hot path calls qt_gemm3_launch from cholesky.hip) ----
