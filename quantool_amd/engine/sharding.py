@@ -331,7 +331,7 @@ def gptq_quantize_row_split(weights: Sequence[torch.Tensor], acc, qargs, *, grou
     bufs = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(bufs, send, group=group)
     bufs = [buf.to(dev) for buf in bufs]
-    failed = [r for r in range(world) if int(bufs[r][0].item()) != 0]
+    failed = [r for r, flag in enumerate(torch.stack([buf[0] for buf in bufs]).tolist()) if flag != 0]     # one host read
     if failed:
         raise RuntimeError(f"row-split gather: rank(s) {failed} produced outputs whose layout differs from the one every "
                            f"rank derives from the arguments" + (f" (here: {layout_error})" if layout_error else ""))
