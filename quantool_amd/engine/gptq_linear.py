@@ -98,10 +98,22 @@ class HessianAccumulator:
         self._fill += t
 
     def _gram(self, rows: torch.Tensor) -> None:
-        if rows.dtype == torch.float32:
-            ops.xtx_accumulate_f32(rows, self._G)
+        # QT_XTX_LAUNCH_TOKENS=n (0 = off, the default): at most n tokens per Gram launch.  The kernel adds all tokens of
+        # a launch into ONE fp32 accumulator per tile element; upstream adds one 384-token product per sample into H.  Both
+        # are fp32 sums of the same exact products, but the long chain's rounding error grows with sqrt(tokens): against
+        # the fp64 Gram the default is 2.5e-6 of sqrt(Hii Hjj) at K = 14336 where upstream's order gives 7e-7 (DESIGN.md
+        # 2.0).  Launches of n tokens make it a two-level sum (partial sums of n, then their sum), at the price of one
+        # read-modify-write of G per launch (K = 14336: 0.2 ms each).
+        limit = _launch_token_limit()
+        if limit <= 0 or rows.shape[0] <= limit:
+            chunks = [rows]
         else:
-            ops.xtx_accumulate(rows, self._G)
+            chunks = [rows[t0:t0 + limit] for t0 in range(0, rows.shape[0], limit)]
+        for part in chunks:
+            if part.dtype == torch.float32:
+                ops.xtx_accumulate_f32(part, self._G)
+            else:
+                ops.xtx_accumulate(part, self._G)
 
     def flush(self) -> None:
         if self._fill:
@@ -116,6 +128,15 @@ class HessianAccumulator:
         self._fill = 0
         self._G.zero_()
         self.n = 0
+
+
+def _launch_token_limit() -> int:
+    import os
+
+    try:
+        return max(0, int(os.environ.get("QT_XTX_LAUNCH_TOKENS", "0") or 0)) // 64 * 64
+    except ValueError:
+        return 0
 
 
 @dataclass
