@@ -101,3 +101,21 @@ def test_wide_batch_after_16_bit_batches_goes_through_the_policy(monkeypatch, ca
         acc.add(torch.randn(384, 64))
     acc.flush()
     assert calls == [("x16", torch.bfloat16, 2 * 384)]
+
+
+def test_launch_token_limit_splits_a_gram_pass_into_two_level_sums(monkeypatch):
+    """QT_XTX_LAUNCH_TOKENS=n: at most n tokens per Gram launch (a two-level fp32 sum); 0 / unset: one
+    launch per staged buffer or direct batch."""
+    acc, calls = _patched_accumulator(monkeypatch, stage_tokens=1024)
+    acc.add(torch.randn(2000, 64).to(torch.bfloat16))                   # direct batch, no limit: one launch
+    assert calls == [("x16", torch.bfloat16, 2000)]
+    monkeypatch.setenv("QT_XTX_LAUNCH_TOKENS", "700")                   # rounded down to a multiple of 64: 640
+    acc.add(torch.randn(2000, 64).to(torch.bfloat16))
+    assert [c[2] for c in calls[1:]] == [640, 640, 640, 80]
+    for _ in range(3):                                                  # staged batches flush through the same limit
+        acc.add(torch.randn(300, 64).to(torch.bfloat16))
+    acc.flush()
+    assert [c[2] for c in calls[5:]] == [640, 260]
+    monkeypatch.setenv("QT_XTX_LAUNCH_TOKENS", "not-a-number")
+    acc.add(torch.randn(2000, 64).to(torch.bfloat16))
+    assert calls[-1][2] == 2000
