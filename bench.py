@@ -44,6 +44,9 @@ import torch  # noqa: E402
 N_SAMPLES = 512
 SEQ_LEN = 384
 REHEARSE = os.environ.get("QT_BENCH_REHEARSE_GLOO") == "1"   # see main(): N>1 control flow on a one-GPU box
+# --gpus 1 with a ONE-rank RCCL group: the barriers, the warm-up and final gather and the max-over-ranks reduction of
+# the N>1 path on the real backend (device tensors, RCCL dtypes) -- all a one-GPU box can show of it
+ONE_RANK_RCCL = os.environ.get("QT_BENCH_ONE_RANK_RCCL") == "1"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
@@ -512,11 +515,12 @@ def main():
                               "self_launched": os.environ.get("QT_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
         return
     dist = None
-    if world > 1:
+    if world > 1 or ONE_RANK_RCCL:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if REHEARSE:
             # one-GPU rehearsal of the N>1 control flow: every rank on cuda:0, gloo for the host side
             # (RCCL refuses two ranks on one device).  Numbers from this mode are not benchmark results.
@@ -745,7 +749,7 @@ def main():
             "value": value, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "per_rank_compute_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
-            "gather_ms": round((elapsed - max(per_rank)) * 1e3, 3) if world > 1 else 0.0,
+            "gather_ms": round((elapsed - max(per_rank)) * 1e3, 3) if dist is not None else 0.0,
             "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
             "layers_in_flight": args.lanes,
             "allocator_calls_in_timed_region": allocator,
@@ -756,7 +760,8 @@ def main():
             "config": {
                 "workload": workload, "model": args.model, "method": args.method,
                 "n_calibration_samples": args.samples, "seq_len": SEQ_LEN, "accumulate": args.accumulate,
-                "layers_per_step_per_gpu": 1, "sharding": f"layers over {world} rank(s), RCCL gather of packed state",
+                "layers_per_step_per_gpu": 1, "sharding": f"layers over {world} rank(s), RCCL gather of packed state"
+                                                       + (" (one-rank RCCL group)" if ONE_RANK_RCCL and world == 1 else ""),
             },
             "roofline": roofline,
             "stages_ms_isolated": stages,
