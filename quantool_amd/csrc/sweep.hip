@@ -250,22 +250,38 @@ constexpr int QPF = 3;   // macro-steps (of 4 columns) a lane's scale / zero-poi
 
 struct QuadState {
     float w[QM], sc[QM], zz[QM];   // sc / zz: only entries M0 .. M0 + QPF are live at macro-step M0
+    float u[2][QM], d[2];          // this lane's U values and the diagonal entry of step C in u[C & 1] / d[C & 1]: read one step ahead
     float lsum, qv, ev, dv;
 };
+
+// this lane's U values of step C (columns 4m + p, m >= C / 4) and U[C][C], from LDS into the registers of parity C & 1
+template <int C>
+__device__ __forceinline__ void quad_fetch(QuadState& s, const float* __restrict__ Up, const float* __restrict__ dd, int p) {
+    if constexpr (C < BS) {
+        constexpr int M0 = C >> 2;
+        const f32x4* urow = (const f32x4*)(Up + C * UP_C + p * UP_P);
+#pragma unroll
+        for (int k4 = M0 >> 2; k4 < QM / 4; ++k4) {
+            const f32x4 t = urow[k4];
+            s.u[C & 1][4 * k4 + 0] = t[0]; s.u[C & 1][4 * k4 + 1] = t[1]; s.u[C & 1][4 * k4 + 2] = t[2]; s.u[C & 1][4 * k4 + 3] = t[3];
+        }
+        s.d[C & 1] = dd[C];
+    }
+}
 
 template <int M0, int P0>
 __device__ __forceinline__ void quad_step(QuadState& s, const float* __restrict__ Up, const float* __restrict__ dd,
                                           int p, float qmin, float qmax) {
     constexpr int C = 4 * M0 + P0;
-    // this lane's U values of step C: columns 4m + p, m >= M0
-    float u[QM];
-    const f32x4* urow = (const f32x4*)(Up + C * UP_C + p * UP_P);
-#pragma unroll
-    for (int k4 = M0 >> 2; k4 < QM / 4; ++k4) {
-        const f32x4 t = urow[k4];
-        u[4 * k4 + 0] = t[0]; u[4 * k4 + 1] = t[1]; u[4 * k4 + 2] = t[2]; u[4 * k4 + 3] = t[3];
-    }
-    const float d = dd[C];
+    // The LDS reads of step C + 1 are issued before step C's arithmetic (a lone wave per SIMD has nothing else to cover
+    // their latency with; rows beyond a ragged block's last column are zero-filled, so the read ahead is always valid)
+#if !defined(QT_SWEEP_LAB) || QT_SWEEP_LAB != 4     // lab build 4: the reads of a step at its own start, as up to round 4
+    quad_fetch<C + 1>(s, Up, dd, p);
+#else
+    quad_fetch<C>(s, Up, dd, p);
+#endif
+    const float* u = s.u[C & 1];
+    const float d = s.d[C & 1];
     // the quantise step on this lane's own column-M0 value (final only in the owner lane)
     const float wv = s.w[M0];
     float x = wv / s.sc[M0];
@@ -314,6 +330,13 @@ struct QuadScales {
 
 template <int M>
 __device__ __forceinline__ void quad_load_scales(QuadState& s, const QuadScales& q) {
+#if defined(QT_SWEEP_LAB) && QT_SWEEP_LAB == 3     // lab build 3 (timing only): no scale / zero-point loads inside the loop
+    if constexpr (M >= QPF && M < QM) {
+        s.sc[M] = s.sc[M - QPF];
+        s.zz[M] = s.zz[M - QPF];
+        return;
+    }
+#endif
     if constexpr (M < QM) {
         const int g = q.gcol[M < q.nm ? 4 * M : 0];
         s.sc[M] = q.scale_t[(size_t)g * q.R];
@@ -341,7 +364,11 @@ __device__ __forceinline__ void quad_macro_step(QuadState& s, const QuadScales& 
         s.lsum = s.lsum + quad_bcast<2>(t);
         s.lsum = s.lsum + quad_bcast<3>(t);
     }
+#if defined(QT_SWEEP_LAB) && QT_SWEEP_LAB == 2     // lab build 2 (timing only): no stores inside the loop
+    if (valid && M0 == QM - 1) {
+#else
     if (valid) {
+#endif
         const int c = 4 * M0 + p;
         Qt[(size_t)(i1 + c) * R + row] = (int8_t)s.qv;
         ErrT[(size_t)c * R + row] = s.ev;
@@ -425,8 +452,11 @@ __global__ __launch_bounds__(QTHREADS) void sweep_quad_kernel(float* __restrict_
     s.ev = 0.0f;
     s.dv = 0.0f;
     __syncthreads();
+    quad_fetch<0>(s, Up, dd, p);
 
+#if !defined(QT_SWEEP_LAB) || QT_SWEEP_LAB != 1   // lab build 1 (tools/sweep_lab.sh, timing only): prologue + epilogue alone
     quad_run<0>(s, qs, Up, dd, p, qmin, qmax, valid, row, R, i1, nm, Qt, ErrT);
+#endif
 
     if (valid) {   // dequantised values back to W (upstream: W[:, i1:i2] = Q1)
         float* wrow = W + (size_t)row * K + i1 + p;
