@@ -30,7 +30,15 @@ HIPCC_FLAGS = [
     "-fno-fast-math",
     "-Wall",
     "-Wno-unused-function",
+    # per-kernel register / scratch / LDS figures as compiler remarks: parsed by _resources() below, not printed
+    "-Rpass-analysis=kernel-resource-usage",
 ]
+
+# Kernels allowed to use scratch (private memory): none.  Round 4 found every sgemm_tn_kernel variant holding its 264-byte
+# argument struct in scratch -- the kernel modified the by-value struct and indexed an array in it at run time, so
+# every pointer and pitch inside the k-loop became a scratch load; the chains' small products ran 10-25 % longer and
+# nothing failed.  Now any kernel with a private segment fails the build.
+SCRATCH_OK: tuple = ()
 
 # lab builds: extra flags (e.g. QT_EXTRA_HIPCC_FLAGS=-DQT_XTX_ABLATION for tools/xtx_wrap_sweep.sh); part of the stamp
 HIPCC_FLAGS += os.environ.get("QT_EXTRA_HIPCC_FLAGS", "").split()
@@ -66,10 +74,52 @@ def _compile(src: Path) -> Path:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{res.stdout}\n{res.stderr}")
-    if res.stderr.strip():
-        sys.stderr.write(res.stderr)
+    rest = _resources(src, res.stderr)
+    if rest.strip():
+        sys.stderr.write(rest)
     stamp.write_text(want)
     return obj
+
+
+def _resources(src: Path, stderr: str) -> str:
+    """Split the kernel-resource-usage remarks out of hipcc's stderr: one line per kernel goes to
+    ``_obj/<stem>.resources.txt`` (name, VGPRs, AGPRs, scratch bytes per lane, spills, LDS bytes, waves per SIMD), a kernel
+    with scratch that is not in SCRATCH_OK fails the build.  Returns what is left of stderr (real warnings)."""
+    import re
+
+    kernels, cur, rest = [], None, []
+    lines = stderr.splitlines()
+    i = 0
+    while i < len(lines):
+        line = lines[i]
+        m = re.search(r"remark:\s+(.*?) \[-Rpass-analysis=kernel-resource-usage\]", line)
+        if m:
+            kv = m.group(1).strip()
+            if kv.startswith("Function Name:"):
+                cur = {"name": kv.split(":", 1)[1].strip()}
+                kernels.append(cur)
+            elif cur is not None and ":" in kv:
+                k, v = kv.rsplit(":", 1)
+                cur[k.strip()] = v.strip()
+            # the remark is followed by a source excerpt and a caret line on its first occurrence per location
+            while i + 1 < len(lines) and re.match(r"^\s+\d* ?\|", lines[i + 1]):
+                i += 1
+        elif not re.match(r"^\d+ (warning|remark)s? generated", line.strip()) and "remarks generated" not in line:
+            rest.append(line)
+        i += 1
+    rows = []
+    for k in kernels:
+        rows.append(f"{k['name']}\tvgpr {k.get('VGPRs', '?')}\tagpr {k.get('AGPRs', '?')}\tscratch "
+                    f"{k.get('ScratchSize [bytes/lane]', '?')}\tvgpr_spill {k.get('VGPRs Spill', '?')}\tlds "
+                    f"{k.get('LDS Size [bytes/block]', '?')}\twaves_per_simd {k.get('Occupancy [waves/SIMD]', '?')}")
+    (OBJ_DIR / (src.stem + ".resources.txt")).write_text("\n".join(rows) + ("\n" if rows else ""))
+    bad = [k["name"] for k in kernels
+           if k.get("ScratchSize [bytes/lane]", "0") not in ("0", "?") and not any(ok in k["name"] for ok in SCRATCH_OK)]
+    if bad:
+        raise RuntimeError(f"{src.name}: kernel(s) with a private segment (scratch): {bad} -- see "
+                           f"{OBJ_DIR / (src.stem + '.resources.txt')}; a by-value argument struct that is modified and "
+                           "indexed at run time, or a register array indexed at run time, is the usual cause")
+    return "\n".join(rest) + ("\n" if rest else "")
 
 
 def audit_m0(src: Path) -> None:

@@ -4,11 +4,22 @@
 // 32 consecutive floats per lane half) and zero-filled at every edge, so any M, N, k works.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sgemm_tn.h"
 
 namespace {
 
 constexpr int BK = 16;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
+template <int N, class F>
+__device__ __forceinline__ void sg_static_for(F&& f) {
+    if constexpr (N > 0) {
+        sg_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 // amdgpu_waves_per_eu(2): the MODE_SUB variants hold a C tile next to the accumulators; capping the
 // register budget at two waves per SIMD makes hipcc park the excess in AGPRs instead of taking all
@@ -18,7 +29,7 @@ constexpr int BK = 16;
 // the f32 MFMA pipe measured 61 % busy at two waves per SIMD on the sweep's k = 512 updates (PMC,
 // profiles/r02_gemm_pmc.txt).  Per output element the k order is unchanged (bit-identical results).
 template <int BM, int BN, int MODE, bool CHAIN = false, int NWAVE = 4>
-__global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAVE == 8 ? 4 : 2))) void sgemm_tn_kernel(SgemmArgs p) {  // p is modified per z-slice
+__global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAVE == 8 ? 4 : 2))) void sgemm_tn_kernel(const SgemmArgs p) {
     constexpr int NT = 64 * NWAVE;
     constexpr int WGM = NWAVE == 8 ? 4 : 2, WGN = 2;          // wave grid
     constexpr int WM = BM / (32 * WGM), WN = BN / (32 * WGN);  // 32x32 sub-tiles per wave in m / n
@@ -32,19 +43,26 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
     const int wave_m = wave >> 1, wave_n = wave & 1;   // WGN == 2
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     if (p.upper_only && m0 >= n0 + BN) return;   // every row of this tile lies below every column: not wanted
+    // The argument block stays untouched (const): a kernel that modifies its by-value struct AND indexes an array in it at
+    // run time gets the whole struct copied to scratch -- every operand pointer and pitch inside the k-loop was a scratch load in
+    // the first round-4 builds (264 B of private segment per lane; the chains' 64x64 products ran 10-25 % longer).
+    const float* Ap = p.A;
+    const float* Bp = p.B;
+    const float* Cinp = p.Cin;
+    float* Coutp = p.Cout;
     int zsplit = blockIdx.z;
     if (p.batch > 1) {        // problem b of a batch of identical shapes: every operand at its own stride
         const int b = zsplit / p.n_splits;
         zsplit -= b * p.n_splits;
-        p.A += (size_t)b * p.bsA;
-        p.B += (size_t)b * p.bsB;
-        if (p.Cin) p.Cin += (size_t)b * p.bsCin;
-        p.Cout += (size_t)b * p.bsCout;
+        Ap += (size_t)b * p.bsA;
+        Bp += (size_t)b * p.bsB;
+        if (Cinp) Cinp += (size_t)b * p.bsCin;
+        Coutp += (size_t)b * p.bsCout;
     }
     if (p.n_groups > 0) {     // stacked rows: the B operand of this tile's row group (boundaries are multiples of BM)
         int g = 0;
         while (g + 1 < p.n_groups && m0 >= p.group_m_end[g]) ++g;
-        p.B += (size_t)g * p.group_bsB;
+        Bp += (size_t)g * p.group_bsB;
     }
     const bool tile_inside = p.fast_interior && m0 + BM <= p.M && n0 + BN <= p.N;   // wave-uniform
 
@@ -55,30 +73,45 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
         const int lo = zsplit * p.k_chunk, hi = lo + p.k_chunk;
         k_begin = k_begin > lo ? k_begin : lo;
         k_end = k_end < hi ? k_end : hi;
-        p.Cout += (size_t)zsplit * (size_t)p.M * (size_t)p.N;
+        Coutp += (size_t)zsplit * (size_t)p.M * (size_t)p.N;
     }
 
-    const bool a_vec = (p.lda % 4 == 0) && (((uintptr_t)p.A & 15) == 0);
-    const bool b_vec = (p.ldb % 4 == 0) && (((uintptr_t)p.B & 15) == 0);
+    const bool a_vec = (p.lda % 4 == 0) && (((uintptr_t)Ap & 15) == 0);
+    const bool b_vec = (p.ldb % 4 == 0) && (((uintptr_t)Bp & 15) == 0);
 
-    f32x4 ra[A4], rb[B4];
+    // Global loads in flight: PD k-steps for the 64x64 tile (one float4 per operand and thread per step, so a deeper ring
+    // is cheap there; a step is only 8 MFMAs per wave).  Measured once the argument struct was out of scratch (below):
+    // PD = 2 / 4 / 8 give the same chain times (K = 4096: 3.09-3.11 / 3.13 / 3.17 ms, K = 14336: 21.1 / 21.3 / 21.3) -- the
+    // 64x64 products are bound by their C read, first panel and store, not by the k-loop's loads.  PD = 2 with the
+    // branch-free fast loop is kept; the larger tiles (32+ MFMAs per step) keep PD = 1.  Same k order: bit-identical.
+#ifndef QT_SGEMM_PD
+#define QT_SGEMM_PD 2
+#endif
+    constexpr int PD = (BM == 64 && BN == 64 && !CHAIN) ? QT_SGEMM_PD : 1;
+    static_assert(PD == 1 || PD % 2 == 0, "the LDS buffer of a step is s & 1: the unrolled ring must be even");
+    f32x4 ra[PD][A4], rb[PD][B4];
 
     // whole tile inside the matrices and 16-byte loads legal: the k-steps that are also inside the
     // k range take straight vector loads (no per-element edge tests in the steady state); the C
     // prefetch and the epilogue of such a tile skip their bounds tests too
     const bool interior = p.fast_interior && a_vec && b_vec && m0 + BM <= p.M && n0 + BN <= p.N;
-    auto gload = [&](int k0) {
+    auto gload_fast = [&](int k0, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+        for (int r = 0; r < A4; ++r) {
+            const int idx = tid + NT * r;
+            ra[slot][r] = *(const f32x4*)(Ap + (size_t)(k0 + idx / (BM / 4)) * p.lda + m0 + (idx % (BM / 4)) * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < B4; ++r) {
+            const int idx = tid + NT * r;
+            rb[slot][r] = *(const f32x4*)(Bp + (size_t)(k0 + idx / (BN / 4)) * p.ldb + n0 + (idx % (BN / 4)) * 4);
+        }
+    };
+    auto gload = [&](int k0, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
         if (interior && k0 + BK <= k_end) {
-#pragma unroll
-            for (int r = 0; r < A4; ++r) {
-                const int idx = tid + NT * r;
-                ra[r] = *(const f32x4*)(p.A + (size_t)(k0 + idx / (BM / 4)) * p.lda + m0 + (idx % (BM / 4)) * 4);
-            }
-#pragma unroll
-            for (int r = 0; r < B4; ++r) {
-                const int idx = tid + NT * r;
-                rb[r] = *(const f32x4*)(p.B + (size_t)(k0 + idx / (BN / 4)) * p.ldb + n0 + (idx % (BN / 4)) * 4);
-            }
+            gload_fast(k0, slot_c);
             return;
         }
 #pragma unroll
@@ -88,7 +121,7 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
             const int k = k0 + kr, m = m0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k < k_end) {
-                const float* src = p.A + (size_t)k * p.lda + m;
+                const float* src = Ap + (size_t)k * p.lda + m;
                 if (a_vec && m + 3 < p.M) {
                     v = *(const f32x4*)src;
                 } else {
@@ -97,7 +130,7 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
                         if (m + e < p.M) v[e] = src[e];
                 }
             }
-            ra[r] = v;
+            ra[slot][r] = v;
         }
 #pragma unroll
         for (int r = 0; r < B4; ++r) {
@@ -106,7 +139,7 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
             const int k = k0 + kr, n = n0 + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k < k_end) {
-                const float* src = p.B + (size_t)k * p.ldb + n;
+                const float* src = Bp + (size_t)k * p.ldb + n;
                 if (b_vec && n + 3 < p.N) {
                     v = *(const f32x4*)src;
                 } else {
@@ -115,19 +148,20 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
                         if (n + e < p.N) v[e] = src[e];
                 }
             }
-            rb[r] = v;
+            rb[slot][r] = v;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
         for (int r = 0; r < A4; ++r) {
             const int idx = tid + NT * r;
-            *(f32x4*)&As[buf][idx / (BM / 4)][(idx % (BM / 4)) * 4] = ra[r];
+            *(f32x4*)&As[buf][idx / (BM / 4)][(idx % (BM / 4)) * 4] = ra[slot][r];
         }
 #pragma unroll
         for (int r = 0; r < B4; ++r) {
             const int idx = tid + NT * r;
-            *(f32x4*)&Bs[buf][idx / (BN / 4)][(idx % (BN / 4)) * 4] = rb[r];
+            *(f32x4*)&Bs[buf][idx / (BN / 4)][(idx % (BN / 4)) * 4] = rb[slot][r];
         }
     };
 
@@ -153,19 +187,27 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wave_m * (BM / WGM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int col = n0 + wave_n * (BN / WGN) + j * 32 + l31;
-                    cpre[i][j][r] = (tile_inside || (row < p.M && col < p.N)) ? p.Cin[(size_t)row * p.ldcin + col] : 0.0f;
+                    cpre[i][j][r] = (tile_inside || (row < p.M && col < p.N)) ? Cinp[(size_t)row * p.ldcin + col] : 0.0f;
                 }
     }
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
-    if (nsteps > 0) {
-        gload(k_begin);
-        lstore(0);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nsteps) gload(k_begin + (s + 1) * BK);
+    // one k-step: refill the register slot this step's panel came from with the panel PD steps ahead, run the step's
+    // MFMAs from LDS, move the next step's panel (requested PD - 1 steps ago) into the other LDS buffer
+    // FAST (whole tile and whole k-steps inside, nsteps % PD == 0): no branch in the step -- the refill is clamped to the
+    // last panel and the last step's LDS store goes to the buffer nobody reads again -- so the compiler's s_waitcnt
+    // counts stay counts (a conditional load or the edge path in the loop makes every wait a vmcnt(0))
+    auto kstep = [&](int s, auto u_c, auto fast_c) {
+        constexpr int u = decltype(u_c)::value;                // s % PD, static: registers cannot be indexed at run time
+        constexpr bool FAST = decltype(fast_c)::value;
+        const int buf = s & 1;
+        if constexpr (FAST) {
+            const int sn = s + PD < nsteps ? s + PD : nsteps - 1;
+            gload_fast(k_begin + sn * BK, std::integral_constant<int, u>{});
+        } else {
+            if (s + PD < nsteps) gload(k_begin + (s + PD) * BK, std::integral_constant<int, u>{});
+        }
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
+        for (int kk = 0; kk < BK / 2; ++kk) {
                 float a[WM], b[WN];
 #pragma unroll
                 for (int i = 0; i < WM; ++i) a[i] = As[buf][2 * kk + h][wave_m * (BM / WGM) + i * 32 + l31];
@@ -177,24 +219,41 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-            if (s + 1 < nsteps) lstore(buf ^ 1);
-            if (CHAIN && s + 1 < nsteps && ((s + 1) * BK) % p.chain_len == 0) {
-                // end of a chain: fold it into the C registers and start the next one from zero
-                // (one 32x32 accumulator at a time, so only 16 extra registers are live)
+        if (FAST || s + 1 < nsteps) lstore(buf ^ 1, std::integral_constant<int, (u + 1) % PD>{});
+        if (CHAIN && s + 1 < nsteps && ((s + 1) * BK) % p.chain_len == 0) {
+            // end of a chain: fold it into the C registers and start the next one from zero
+            // (one 32x32 accumulator at a time, so only 16 extra registers are live)
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) {
+                for (int j = 0; j < WN; ++j) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            cpre[i][j][r] = cpre[i][j][r] - acc[i][j][r];
-                            acc[i][j][r] = 0.0f;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int r = 0; r < 16; ++r) {
+                        cpre[i][j][r] = cpre[i][j][r] - acc[i][j][r];
+                        acc[i][j][r] = 0.0f;
                     }
-            }
-            __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    if (PD > 1 && interior && nsteps > 0 && nsteps % PD == 0 && (k_end - k_begin) % BK == 0) {
+        sg_static_for<PD>([&](auto d) { gload_fast(k_begin + decltype(d)::value * BK, d); });
+        lstore(0, I0{});
+        __syncthreads();
+        for (int s0 = 0; s0 < nsteps; s0 += PD)           // buf = s & 1 stays right because PD is even
+            sg_static_for<PD>([&](auto u) { kstep(s0 + decltype(u)::value, u, std::true_type{}); });
+    } else if (nsteps > 0) {
+        sg_static_for<PD>([&](auto d) {
+            if (decltype(d)::value < nsteps) gload(k_begin + decltype(d)::value * BK, d);
+        });
+        lstore(0, I0{});
+        __syncthreads();
+        for (int s0 = 0; s0 < nsteps; s0 += PD)
+            sg_static_for<PD>([&](auto u) {
+                if (s0 + decltype(u)::value < nsteps) kstep(s0 + decltype(u)::value, u, std::false_type{});
+            });
     }
 
 #pragma unroll
@@ -209,7 +268,7 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
                     float v = acc[i][j][r];
                     if (MODE == SG_MODE_SUB) v = cpre[i][j][r] - v;
                     if (MODE == SG_MODE_NEG) v = -v;
-                    p.Cout[(size_t)row * p.ldcout + col] = v;
+                    Coutp[(size_t)row * p.ldcout + col] = v;
                 }
             }
 }
