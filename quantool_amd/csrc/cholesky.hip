@@ -514,6 +514,74 @@ __global__ __launch_bounds__(128) void trinv_batched_kernel(const float* __restr
     }
 }
 
+// The same outputs on the f32 MFMA (round 4; QT_CHOL_TRINV=div selects the kernel above): Z = R^-T I by trsm_rt_kernel's
+// blocked forward substitution with the 32x32 inverses potf2 already computed -- four stages of MFMAs instead of 128
+// sequential divide-and-update steps (97 -> ~20 us per launch at K = 4096, 137 -> ~25 at K = 14336; one launch per chain).
+// Z is lower triangular: Ydiag(b) = Z, Dinv[b] = Z^T.  Wave w owns the columns 32w .. 32w + 31 of the identity.
+__global__ __launch_bounds__(256) void trinv_mfma_kernel(const float* __restrict__ Rd_all, int K,
+                                                         float* __restrict__ Dinv_all,
+                                                         float* __restrict__ Y, int64_t ldy, int64_t bsW, int64_t bsY) {
+    if (blockIdx.y) {      // problem b of a batch
+        Rd_all += (size_t)blockIdx.y * bsW;
+        Dinv_all += (size_t)blockIdx.y * bsW;
+        Y += (size_t)blockIdx.y * bsY;
+    }
+    extern __shared__ __attribute__((aligned(16))) float Rs[];  // [RD_STRIDE]
+    const int blk = blockIdx.x;
+    const int n = (K - blk * NB < NB) ? K - blk * NB : NB;
+    const float* Rd = Rd_all + (size_t)blk * RD_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < RD_STRIDE / 4; e += 256) ((f32x4*)Rs)[e] = ((const f32x4*)Rd)[e];
+    const float* D32 = Rs + NB * NB;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int col = wave * 32 + l31;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+            acc[a][r] = (row == col) ? 1.0f : 0.0f;
+        }
+    __syncthreads();
+
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        f32x16 zb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zb[r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float av = D32[(b * 32 + k) * 32 + l31];  // X_b[k][i = l31]
+            zb = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc[b][r], zb, 0, 0, 0);
+        }
+        acc[b] = zb;
+#pragma unroll
+        for (int a = b + 1; a < 4; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float av = -Rs[(32 * b + k) * NB + 32 * a + l31];  // -R[32b+k][32a+i]
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, zb[r], acc[a], 0, 0, 0);
+            }
+        }
+    }
+    float* Dinv = Dinv_all + (size_t)blk * NB * NB;
+    float* Yd = Y + (size_t)(blk * NB) * ldy + blk * NB;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool in = row < n && col < n;
+            const float z = (in && row >= col) ? acc[a][r] : 0.0f;      // Z[row][col] = (R^-1)[col][row]
+            Dinv[col * NB + row] = z;
+            if (in) Yd[(size_t)row * ldy + col] = z;
+        }
+}
+
 // XT[k][m] = Y_II[m][k] for a w x w diagonal block of the lower-triangular Y (entries above the diagonal
 // of Y are not initialised outside the 128-blocks on the diagonal: written as zeros here)
 __global__ __launch_bounds__(256) void transpose_lower_block_kernel(const float* __restrict__ Y, int64_t ldy, int w,
@@ -562,11 +630,12 @@ __global__ __launch_bounds__(256) void flat_reverse_lower_to_upper_kernel(float*
 // if the factorisation hit a non-positive pivot, U = I (plain round-to-nearest).
 __global__ __launch_bounds__(256) void identity_if_failed_kernel(float* __restrict__ U, int K,
                                                                  const int32_t* __restrict__ info, int64_t bsU) {
+    // a fixed, small grid striding over the rows: in the normal case (info == 0) every workgroup leaves at once, and a
+    // launch of K * K / 256 workgroups that all do so took 141 us at K = 14336 (16 us at K = 4096) for nothing
     if (info[blockIdx.z] == 0) return;
     U += (size_t)blockIdx.z * bsU;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j < K) U[(size_t)i * K + j] = (i == j) ? 1.0f : 0.0f;
+    for (int i = blockIdx.x; i < K; i += gridDim.x)
+        for (int j = threadIdx.x; j < K; j += blockDim.x) U[(size_t)i * K + j] = (i == j) ? 1.0f : 0.0f;
 }
 
 }  // namespace
@@ -685,6 +754,9 @@ static int chol_run(float* A, int64_t strideA, int K, float* U, int64_t strideU,
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)trinv_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)inv_lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trinv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(RD_STRIDE * sizeof(float)));
         return e;
     }));
     QT_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * nprob, stream));
@@ -762,8 +834,15 @@ static int chol_run(float* A, int64_t strideA, int K, float* U, int64_t strideU,
         }
     }
     // ---- all diagonal-block inverses at once ----
-    hipLaunchKernelGGL(trinv_batched_kernel, dim3(nblk, nprob), dim3(NB), inv_lds, stream, (const float*)Rd, K, Dinv, Y,
-                       (int64_t)K, sW, sY);
+    {
+        const char* e = getenv("QT_CHOL_TRINV");   // read per call: the tests compare the two kernels in one process
+        if (e && strcmp(e, "div") == 0)
+            hipLaunchKernelGGL(trinv_batched_kernel, dim3(nblk, nprob), dim3(NB), inv_lds, stream, (const float*)Rd, K, Dinv, Y,
+                               (int64_t)K, sW, sY);
+        else
+            hipLaunchKernelGGL(trinv_mfma_kernel, dim3(nblk, nprob), dim3(256), RD_STRIDE * sizeof(float), stream,
+                               (const float*)Rd, K, Dinv, Y, (int64_t)K, sW, sY);
+    }
     QT_LAUNCH_CHECK();
     // ---- Y = R^-T by NBI-row block rows ----
     for (int I0 = 0, Ib = 0; I0 < K; I0 += NBI, ++Ib) {
@@ -831,7 +910,7 @@ static int chol_run(float* A, int64_t strideA, int K, float* U, int64_t strideU,
     }
     hipLaunchKernelGGL(flat_reverse_lower_to_upper_kernel, dim3((K + 255) / 256, K, nprob), dim3(256), 0, stream, U, K, sU);
     QT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(identity_if_failed_kernel, dim3((K + 255) / 256, K, nprob), dim3(256), 0, stream, U, K,
+    hipLaunchKernelGGL(identity_if_failed_kernel, dim3(K < 1024 ? K : 1024, 1, nprob), dim3(256), 0, stream, U, K,
                        (const int32_t*)info, sU);
     QT_LAUNCH_CHECK();
     return QT_OK;

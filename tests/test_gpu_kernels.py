@@ -342,6 +342,20 @@ def test_cholesky_bf16x3_products_wide_dynamic_range(ops, oracle, dev, monkeypat
     assert errs["bf16x3"] <= max(4 * errs["f32"], 5e-6)
 
 
+@pytest.mark.parametrize("K", [200, 1000, 2048])
+def test_cholesky_diagonal_block_inverses_on_the_mfma(ops, oracle, dev, K, monkeypatch):
+    """The 128x128 diagonal-block inverses come from `trinv_mfma_kernel` (blocked substitution with potf2's 32x32
+    inverses); `QT_CHOL_TRINV=div` selects the divide-and-update kernel of rounds 1-3.  Both must meet the accuracy
+    bar of `_check_factor` (ragged last block included: K = 200, 1000) and agree with each other to fp32 rounding."""
+    monkeypatch.setenv("QT_CHOL_TRINV", "div")
+    base, e0, _ = _check_factor(ops, oracle, dev, K)
+    monkeypatch.delenv("QT_CHOL_TRINV")
+    got, e1, el = _check_factor(ops, oracle, dev, K)
+    print(f"K={K}: max error / max|U| vs fp64: divide-and-update {e0:.2e}, MFMA blocks {e1:.2e}, fp32 LAPACK {el:.2e}")
+    assert not np.array_equal(got, base), "the MFMA kernel was not taken"
+    assert np.abs(got - base).max() <= 2e-5 * np.abs(base).max()
+
+
 @pytest.mark.parametrize("K", [128, 384, 1024])
 def test_cholesky_ignores_the_strict_lower_triangle(ops, oracle, dev, K):
     """`qt_hessian_prepare` writes the upper triangle of the flipped matrix only; whatever the allocation held
