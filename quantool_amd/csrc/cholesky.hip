@@ -387,7 +387,6 @@ __global__ __launch_bounds__(256) void trsm_rt_kernel(const float* __restrict__ 
     }
     extern __shared__ __attribute__((aligned(16))) float Rs[];  // [RD_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < RD_STRIDE / 4; e += 256) ((f32x4*)Rs)[e] = ((const f32x4*)Rd)[e];
     const float* D32 = Rs + NB * NB;
     const int l31 = lane & 31, h = lane >> 5;
     const int col = blockIdx.x * 128 + wave * 32 + l31;
@@ -402,6 +401,18 @@ __global__ __launch_bounds__(256) void trsm_rt_kernel(const float* __restrict__ 
             const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
             acc[a][r] = (row < n) ? B[(size_t)row * ldb + colc] : 0.0f;
         }
+    // R block + sub-block inverses into LDS: all 20 float4 loads of a thread in flight before the first is stored.  As a
+    // load -> wait -> store loop (what `for (e = tid; ...) Rs[e] = Rd[e]` compiles to) the copy paid 20 memory round trips
+    // one after the other -- more than half of this kernel's 17 us (ISA read in round 4; potf2's fill had the same shape).
+    {
+        constexpr int NV = RD_STRIDE / 4 / 256;
+        static_assert(NV * 4 * 256 == RD_STRIDE, "whole float4s per thread");
+        f32x4 v[NV];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) v[r] = ((const f32x4*)Rd)[tid + 256 * r];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) ((f32x4*)Rs)[tid + 256 * r] = v[r];
+    }
     __syncthreads();
 
 #pragma unroll
@@ -531,7 +542,14 @@ __global__ __launch_bounds__(256) void trinv_mfma_kernel(const float* __restrict
     const int n = (K - blk * NB < NB) ? K - blk * NB : NB;
     const float* Rd = Rd_all + (size_t)blk * RD_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < RD_STRIDE / 4; e += 256) ((f32x4*)Rs)[e] = ((const f32x4*)Rd)[e];
+    {   // as in trsm_rt_kernel: every load of the copy in flight before the first store
+        constexpr int NV = RD_STRIDE / 4 / 256;
+        f32x4 v[NV];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) v[r] = ((const f32x4*)Rd)[tid + 256 * r];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) ((f32x4*)Rs)[tid + 256 * r] = v[r];
+    }
     const float* D32 = Rs + NB * NB;
     const int l31 = lane & 31, h = lane >> 5;
     const int col = wave * 32 + l31;
