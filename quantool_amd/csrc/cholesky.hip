@@ -83,12 +83,25 @@ static int chol_g3_min_chunks() {   // read per call: tests switch the path on f
     return x < 1 ? 1 : x;
 }
 
+// Items per product.  A product's k range is cut so that its items fill at most ONE round of the 256 CUs; below K = 8192
+// the cap is 96 (QT_G3_TARGET_ITEMS forces a value for every K): those widths come as batches in practice (3 per Llama
+// layer, 10 per Mixtral layer), a batch of n multiplies the items by n, and fewer, longer items mean fewer slabs to
+// write and reduce.  K = 4096, cap 256 / 128 / 96 / 64: one chain 2.88 / 2.88 / 2.92 / 3.04 ms, three batched 4.15 / 3.92 /
+// 3.84 / 3.59, ten batched 8.67 / 7.63 / 7.30 / 7.15; K = 8192 x 3: 13.4 / 13.6 / 13.8 / 13.4 (no gain: stays at 256).
+// The cap is part of the bits and one value for single and batched calls (a batch stays bit-identical to its members).
+static int chol_g3_target_items(int K) {
+    const char* e = getenv("QT_G3_TARGET_ITEMS");
+    if (e && atoi(e) > 0) return atoi(e);
+    return K < 8192 ? 96 : 256;
+}
+
 static const CholG3Plan* chol_g3_plan(int K, int NBO, int NBI) {
     static std::mutex m;
     static std::map<std::tuple<int, int, int, int>, CholG3Plan*> plans;
     const int min_chunks = chol_g3_min_chunks();
+    const int target_items = chol_g3_target_items(K);
     std::lock_guard<std::mutex> lock(m);
-    const auto key = std::make_tuple(K, NBO, NBI, min_chunks);
+    const auto key = std::make_tuple(K, NBO, NBI, min_chunks * 1024 + target_items);
     auto it = plans.find(key);
     if (it != plans.end()) return it->second;
     CholG3Plan* pl = new CholG3Plan();
@@ -98,7 +111,7 @@ static const CholG3Plan* chol_g3_plan(int K, int NBO, int NBI) {
         if (min_chunks <= 0 || K % 8 != 0 || g3_row_chunks(Tm, Tn, c_end, tri) * G3_CHUNK_ROWS < (long)min_chunks * 128) return st;
         std::vector<G3Item> items;
         std::vector<G3Red> red;
-        g3_plan_row(Tm, Tn, c_end, tri, items, red);
+        g3_plan_row(Tm, Tn, c_end, tri, items, red, target_items);
         st.n_items = (int)items.size();
         st.n_red = (int)red.size();
         st.item_off = qt_align_up(bytes.size(), 256);

@@ -75,4 +75,4 @@ int qt_split3_launch(const float* src, int64_t ld_src, int rows, int cols, unsig
 // 256-blocks: B[k][n] == 0 for k < 256 * tj); split along k into <= 256 items of near-equal length (one round
 // of the 256 CUs), longest first.
 long g3_row_chunks(int Tm, int Tn, int c_end, int tri);
-void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items, std::vector<G3Red>& red);
+void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items, std::vector<G3Red>& red, int target_items = 0);

@@ -382,11 +382,12 @@ long g3_row_chunks(int Tm, int Tn, int c_end, int tri) {
     return total;
 }
 
-void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items, std::vector<G3Red>& red) {
+void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items, std::vector<G3Red>& red, int target_items) {
     constexpr int TRI_STEP = 256 / G3_CHUNK_ROWS;
     items.clear();
     red.clear();
     const long total = g3_row_chunks(Tm, Tn, c_end, tri);
+    const int cap = target_items > 0 && target_items < NUM_CU ? target_items : NUM_CU;   // items per product (at most one round of the CUs)
     // smallest piece length (in chunks, >= 2) with which all pieces fit one round of the 256 CUs
     auto count_items = [&](int per) {
         long n_items = 0;
@@ -396,8 +397,8 @@ void g3_plan_row(int Tm, int Tn, int c_end, int tri, std::vector<G3Item>& items,
         }
         return n_items;
     };
-    int per = std::max(2, (int)((total + NUM_CU - 1) / NUM_CU));
-    while (count_items(per) > NUM_CU && per < c_end) ++per;   // more tiles than CUs: one item per tile
+    int per = std::max(2, (int)((total + cap - 1) / cap));
+    while (count_items(per) > cap && per < c_end) ++per;   // more tiles than the cap: one item per tile
     int next_slab = 0;
     for (int ti = 0; ti < Tm; ++ti)
         for (int tj = 0; tj < Tn; ++tj) {
