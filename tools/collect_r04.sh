@@ -3,10 +3,10 @@
 # Every step writes its own file, so a late failure loses nothing.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r4final
+O=$R/gpurun_out/${COLLECT_DIR:-r4final}
 mkdir -p "$O"
 cd "$R"
-echo "bench default" && python3 bench.py --steps 20 --warmup 3 > "$O/bench_default.json" 2> "$O/bench_default.err" || exit 1
+echo "bench default" && python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_default.json" 2> "$O/bench_default.err" || exit 1
 echo "bench 32 steps" && python3 bench.py --steps 32 --warmup 3 --no-cpu-baseline --no-stage-split > "$O/bench_32steps.json" 2>/dev/null || exit 1
 echo "bench a/b: a chain per group (round 3), 2 layers in flight" && QT_BATCH_CHAINS=0 python3 bench.py --steps 20 --warmup 3 --lanes 2 --no-cpu-baseline --no-stage-split > "$O/bench_ab_unbatched_lanes2.json" 2>/dev/null
 echo "bench a/b: batched, 2 layers in flight" && python3 bench.py --steps 20 --warmup 3 --lanes 2 --no-cpu-baseline --no-stage-split > "$O/bench_ab_batched_lanes2.json" 2>/dev/null
@@ -29,14 +29,16 @@ echo "chol batched kernel breakdown" && mkdir -p "$O/cholprof"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/cholprof" -- python3 "$R/tools/chol_batched.py" 4096 3 1 > "$O/cholprof.log" 2>&1)
 DB=$(ls "$O"/cholprof/*/*results.db | head -1)
 { echo "# one batched chain of 3 x K = 4096 (rocprofv3 --kernel-trace, tools/rocpd_stats.py)"; python3 tools/rocpd_stats.py "$DB" --last-chain flat_reverse --gridz 3; echo; echo "# one single-problem chain, K = 4096"; python3 tools/rocpd_stats.py "$DB" --last-chain flat_reverse --gridz 1; } > "$O/chol_kernel_stats_K4096_batched.txt"
+if [ "${COLLECT_PMC:-1}" = 1 ]; then
 echo "xtx pmc" && bash tools/xtx_pmc.sh "$O/xtx_pmc_K14336" 14336 > /dev/null 2>&1
 bash tools/xtx_pmc.sh "$O/xtx_pmc_K4096" 4096 > /dev/null 2>&1
 cp "$O/xtx_pmc_K14336/summary_K14336.md" "$O/xtx_pmc_K14336.md" 2>/dev/null
 cp "$O/xtx_pmc_K4096/summary_K4096.md" "$O/xtx_pmc_K4096.md" 2>/dev/null
 python3 tools/xtx_traffic_json.py "$O/xtx_pmc_K4096" "$O/xtx_pmc_K14336" > "$O/xtx_pmc_traffic.json" 2> "$O/xtx_pmc_traffic.err"
+fi
 echo "bench profiled" && mkdir -p "$O/benchprof"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/benchprof" -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-stage-split > "$O/bench_profiled.json" 2> "$O/bench_profiled.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/benchprof" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-stage-split > "$O/bench_profiled.json" 2> "$O/bench_profiled.err" || exit 1
 cd "$R"
 python3 tools/xtx_trace_segments.py $(ls "$O"/benchprof/*/*kernel_trace.csv | head -1) "$O/bench_profiled.json" > "$O/bench_xtx_segments.md" 2>&1
 cp $(ls "$O"/benchprof/*/*kernel_stats.csv | head -1) "$O/bench_kernel_stats.csv"
