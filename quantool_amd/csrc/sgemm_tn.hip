@@ -12,6 +12,10 @@ namespace {
 
 constexpr int BK = 16;
 
+#ifndef QT_SGEMM_PD          // k-steps whose global loads are in flight in the 64x64 tile's loop (lab builds: -DQT_SGEMM_PD=n)
+#define QT_SGEMM_PD 2
+#endif
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
 template <int N, class F>
 __device__ __forceinline__ void sg_static_for(F&& f) {
@@ -80,15 +84,12 @@ __global__ __launch_bounds__(64 * NWAVE) __attribute__((amdgpu_waves_per_eu(NWAV
     const bool b_vec = (p.ldb % 4 == 0) && (((uintptr_t)Bp & 15) == 0);
 
     // Global loads in flight: PD k-steps for the 64x64 tile (one float4 per operand and thread per step, so a deeper ring
-    // is cheap there; a step is only 8 MFMAs per wave).  Measured once the argument struct was out of scratch (below):
+    // is cheap there; a step is only 8 MFMAs per wave).  Measured once the argument struct was out of scratch (above):
     // PD = 2 / 4 / 8 give the same chain times (K = 4096: 3.09-3.11 / 3.13 / 3.17 ms, K = 14336: 21.1 / 21.3 / 21.3) -- the
     // k-loop's loads are not what a 64x64 product waits for: a wave's 32x32 output is ONE dependent chain of k / 2
     // MFMAs of 64 cycles each (k = 384: 12.3 k cycles = 5.6 us of a 9-12 us launch), the rest is the C read, the first
     // panel and the store.  PD = 2 with the branch-free fast loop is kept; the larger tiles (32+ MFMAs per step) keep
     // PD = 1.  Same k order: bit-identical.
-#ifndef QT_SGEMM_PD
-#define QT_SGEMM_PD 2
-#endif
     constexpr int PD = (BM == 64 && BN == 64 && !CHAIN) ? QT_SGEMM_PD : 1;
     static_assert(PD == 1 || PD % 2 == 0, "the LDS buffer of a step is s & 1: the unrolled ring must be even");
     f32x4 ra[PD][A4], rb[PD][B4];
