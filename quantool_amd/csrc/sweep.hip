@@ -442,6 +442,9 @@ __global__ __launch_bounds__(QTHREADS) void sweep_quad_kernel(float* __restrict_
 #pragma unroll
         for (int m = 0; m < QM; ++m) s.w[m] = m < nm ? wrow[4 * m] : 0.0f;
     }
+    // the row's running loss, read with the row itself: as `loss[row] = loss[row] + ...` at the end it was one more
+    // memory round trip behind the last column step of every block launch
+    const float loss_in = (valid && p == 0) ? loss[row] : 0.0f;
     const QuadScales qs = {scale_t + rowc, zp_t + rowc, g_idx + i1 + p, R, nm};
     quad_load_scales<0>(s, qs);
     quad_load_scales<1>(s, qs);
@@ -452,6 +455,9 @@ __global__ __launch_bounds__(QTHREADS) void sweep_quad_kernel(float* __restrict_
     s.ev = 0.0f;
     s.dv = 0.0f;
     __syncthreads();
+    // consume the early loss read here, where the row's own loads are waited for anyway: its use at the end would
+    // otherwise carry an s_waitcnt vmcnt(0) that also waits for every store of the write-back to be acknowledged
+    asm volatile("" ::"v"(loss_in));
     quad_fetch<0>(s, Up, dd, p);
 
 #if !defined(QT_SWEEP_LAB) || QT_SWEEP_LAB != 1   // lab build 1 (tools/sweep_lab.sh, timing only): prologue + epilogue alone
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(QTHREADS) void sweep_quad_kernel(float* __restrict_
         for (int m = 0; m < QM; ++m)
             if (m < nm) wrow[4 * m] = s.w[m];
     }
-    if (valid && p == 0) loss[row] = loss[row] + s.lsum / 2.0f;
+    if (valid && p == 0) loss[row] = loss_in + s.lsum / 2.0f;
 }
 
 }  // namespace
