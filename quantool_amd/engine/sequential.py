@@ -471,18 +471,22 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                                f"declares targets={list(qm.targets)}")
             if sq is not None:
                 _smooth_layer(layer, cache, sq.smoothing_strength, dev, sq.mappings, lname)
-            # discovery pass on batch 0: which Linears read the same tensor.  The input tensors are
-            # kept alive until the grouping is done: a freed activation's address can be handed to
-            # a later, unrelated tensor of the same shape, and pointer equality would then lie.
-            seen: Dict[str, torch.Tensor] = {}
+            # Discovery on batch 0: which Linears read the same tensor.  This forward is ALSO batch 0's calibration
+            # forward -- the inputs it shows are kept (that keeps them alive, too: a freed activation's address can be
+            # handed to a later, unrelated tensor of the same shape, and pointer equality would then lie) and go into
+            # the accumulators as soon as the grouping is known.  (Rounds 1-4 ran batch 0 twice: once to discover, once
+            # to accumulate -- a sixth of a calibration pass per layer.)  It runs to its end: the call counts of a
+            # whole forward decide whether the later ones may stop early.
+            seen: Dict[str, List[torch.Tensor]] = {}      # every input a Linear was called with, in call order
             calls: Dict[str, int] = {}
 
             def discover(name):
                 def fn(_m, a):
-                    seen[name] = a[0]
+                    seen.setdefault(name, []).append(a[0])
                     calls[name] = calls.get(name, 0) + 1
                 return fn
 
+            ph.start()
             hooks = [m.register_forward_pre_hook(discover(n)) for n, m in linears.items()]
             args, kwargs = cache[0]
             layer(*args, **kwargs)
@@ -490,15 +494,14 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                 hk.remove()
             groups: Dict[tuple, List[str]] = {}
             for n in linears:
-                t = seen.get(n)
-                if t is None:
+                if n not in seen:
                     # not reached by batch 0 (a sparse-MoE expert none of its tokens was routed to):
                     # sharing cannot be established, so the Linear keeps a Hessian of its own
                     groups[("solo", n)] = [n]
                     continue
+                t = seen[n][0]
                 key = (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), tuple(t.stride()))
                 groups.setdefault(key, []).append(n)
-            seen.clear()
             grouping = list(groups.values())
             if world > 1:
                 # every rank discovered the sharing on ITS batch 0, and a Linear one rank's batch did not reach
@@ -537,12 +540,26 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                         raise _StopForward
                 return fn
 
-            hooks = [linears[lead].register_forward_pre_hook(add_hook(lead)) for lead in leaders]
-            ph.start()
-            for args, kwargs in cache:
+            def set_batch(args):
                 h0 = args[0] if args else None
                 cur["samples"] = int(h0.shape[0]) if torch.is_tensor(h0) and h0.dim() >= 3 else 1
                 cur["tokens_per_sample"] = int(h0.shape[1]) if torch.is_tensor(h0) and h0.dim() >= 3 else None
+
+            # batch 0: what the discovery forward saw, group by group in the order the hooks would have fired
+            # (QT_CALIB_MERGED_DISCOVERY=0: batch 0 is forwarded a second time, as up to round 4 -- A/B only)
+            merged = os.environ.get("QT_CALIB_MERGED_DISCOVERY", "1") != "0"
+            if merged:
+                set_batch(cache[0][0])
+                for lead in [n for n in seen if n in leaders]:
+                    for x in seen[lead]:
+                        if x.dim() >= 3:
+                            accs[lead].add(x.reshape(-1, x.shape[-2], x.shape[-1]))
+                        else:
+                            accs[lead].add(x.unsqueeze(0), num_samples=cur["samples"])
+            seen.clear()
+            hooks = [linears[lead].register_forward_pre_hook(add_hook(lead)) for lead in leaders]
+            for args, kwargs in (cache[1:] if merged else cache):
+                set_batch(args)
                 fired.clear()
                 try:
                     layer(*args, **kwargs)
@@ -622,6 +639,11 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
                         pool.run(lambda lead=lead, names=names: quantize_group(lead, names))
                     else:
                         quantize_group(lead, names)
+            # The chains are joined BEFORE the propagate pass.  (Tried in round 4: no join, every quantised Linear waiting
+            # for its own chain's event in a forward pre-hook, so that a Llama layer's down_proj chain runs beside the
+            # quantised layer's attention and gate / up GEMMs.  One of eight runs of test_gpu_config1_opt.py then
+            # disagreed with the oracle in 6 packed words of the one Linear whose chain overlapped the pass; the cause
+            # was not found, so the overlap is not shipped.)
             if pool is not None:
                 pool.join()
             accs.clear()
