@@ -478,11 +478,13 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             # to accumulate -- a sixth of a calibration pass per layer.)  It runs to its end: the call counts of a
             # whole forward decide whether the later ones may stop early.
             seen: Dict[str, List[torch.Tensor]] = {}      # every input a Linear was called with, in call order
+            seen_version: Dict[str, List[int]] = {}       # ... and its version counter at that moment
             calls: Dict[str, int] = {}
 
             def discover(name):
                 def fn(_m, a):
                     seen.setdefault(name, []).append(a[0])
+                    seen_version.setdefault(name, []).append(a[0]._version)
                     calls[name] = calls.get(name, 0) + 1
                 return fn
 
@@ -548,6 +550,11 @@ def oneshot_module(model, dataset, recipe, dev, *, num_calibration_samples: int,
             # batch 0: what the discovery forward saw, group by group in the order the hooks would have fired
             # (QT_CALIB_MERGED_DISCOVERY=0: batch 0 is forwarded a second time, as up to round 4 -- A/B only)
             merged = os.environ.get("QT_CALIB_MERGED_DISCOVERY", "1") != "0"
+            if merged and any(t._version != v for n in seen for t, v in zip(seen[n], seen_version[n])):
+                # a kept input was written in place later in the forward (its version counter moved): what it holds now
+                # is not what the Linear read.  Forward batch 0 again and take the inputs at hook time, as before.
+                logger.info(f"{lname}: a Linear's input is modified in place behind it; batch 0 is forwarded twice")
+                merged = False
             if merged:
                 set_batch(cache[0][0])
                 for lead in [n for n in seen if n in leaders]:
